@@ -1,0 +1,128 @@
+"""
+PMDArray: array-like view of a decomposition ``Y ~ mean + std * ([U R] diag(s) Vt)``.
+
+Mirrors /root/reference/localmd/pmdarray.py:7-171 (constructor signature, ``u/r/s/v``,
+``mean_img``/``var_img``, ``order``, ``shape``/``dtype``/``ndim``, ``spatial_crop``,
+``temporal_crop``, ``__getitem__``).  One documented deviation: the reference's two-key
+branch (``arr[frames, rows]``) raises TypeError (pmdarray.py:145-149 passes two positional
+arguments to ``spatial_crop``); here it selects rows and all columns.
+
+``save_npz``/``load_npz`` write/read the reference's on-disk layout (README.md:31-62,
+demos/official_demo.ipynb cells 8 and 10).
+"""
+from typing import Union
+
+import numpy as np
+import scipy.sparse
+
+
+class PMDArray:
+    def __init__(self, u, r, s, v, data_shape, data_order, mean_img, std_img):
+        self.order = data_order
+        self.num_frames, self.fov_dim1, self.fov_dim2 = (int(x) for x in data_shape)
+        self._u = u.tocsr()
+        self._r = r
+        self._s = s
+        self._v = v
+        # (R * s) V cached once: __getitem__ is then one sparse-dense product
+        self._combined_temporal = (self._r * self._s[None, :]).dot(self._v)
+        self.mean_img = mean_img
+        self.var_img = std_img  # NB: a noise *std* estimate, stored under the reference's name
+        self.row_indices = np.arange(self.fov_dim1 * self.fov_dim2).reshape(
+            (self.fov_dim1, self.fov_dim2), order=self.order
+        )
+
+    u = property(lambda self: self._u)
+    r = property(lambda self: self._r)
+    s = property(lambda self: self._s)
+    v = property(lambda self: self._v)
+
+    @property
+    def dtype(self):
+        return np.float32
+
+    @property
+    def shape(self):
+        return (self.num_frames, self.fov_dim1, self.fov_dim2)
+
+    @property
+    def ndim(self):
+        return 3
+
+    @staticmethod
+    def _as_list(key):
+        return [key] if isinstance(key, (int, np.integer)) else key
+
+    def spatial_crop(self, key):
+        """key: 2-tuple of row / column selectors -> (u rows (csr), mean, std, implied fov shape)."""
+        if key[0] is None or key[1] is None:
+            raise ValueError("Cannot pass in None for indexing")
+        k0, k1 = self._as_list(key[0]), self._as_list(key[1])
+        used_rows = self.row_indices[k0, k1]
+        mean_used = self.mean_img[k0, k1]
+        var_used = self.var_img[k0, k1]
+        u_used = self._u[used_rows.reshape((-1,), order=self.order)]
+        return u_used, mean_used, var_used, used_rows.shape
+
+    def temporal_crop(self, key: Union[np.ndarray, slice, list, int]) -> np.ndarray:
+        if key is None:
+            raise ValueError("Cannot use None for indexing")
+        return self._combined_temporal[:, self._as_list(key)]
+
+    def __getitem__(self, key) -> np.ndarray:
+        """self[frames], self[frames, rows], self[frames, rows, cols]; no dimension expansion."""
+        if key is None:
+            raise ValueError("Cannot use None for indexing")
+        if not isinstance(key, tuple):
+            key = (key,)
+        everything = slice(None, None, None)
+        if len(key) == 1:
+            skey = (everything, everything)
+        elif len(key) == 2:
+            skey = (key[1], everything)
+        elif len(key) == 3:
+            skey = (key[1], key[2])
+        else:
+            raise ValueError("Too many values to unpack in __getitem__")
+        spatial, mean_used, var_used, fov = self.spatial_crop(skey)
+        temporal = self.temporal_crop(key[0])
+        out = spatial.dot(temporal).reshape(fov + (-1,), order=self.order)
+        out = out * np.expand_dims(var_used, axis=var_used.ndim) + np.expand_dims(mean_used, axis=mean_used.ndim)
+        out = np.transpose(out, axes=(out.ndim - 1, *range(out.ndim - 1)))
+        return out.squeeze().astype(self.dtype)
+
+
+def save_npz(filename, pmd: PMDArray):
+    """Write the reference's .npz layout (notebook cell 8; README.md:31-46)."""
+    U = pmd.u
+    np.savez(
+        filename,
+        fov_shape=pmd.shape[1:],
+        fov_order=pmd.order,
+        U_data=U.data,
+        U_indices=U.indices,
+        U_indptr=U.indptr,
+        U_shape=U.shape,
+        U_format=type(U),
+        R=pmd.r,
+        s=pmd.s,
+        Vt=pmd.v,
+        mean_img=pmd.mean_img,
+        noise_var_img=pmd.var_img,
+    )
+
+
+def load_npz(filename) -> PMDArray:
+    """Read the reference's .npz layout (notebook cell 10; README.md:48-62).  ``U_format`` is
+    an object entry in reference-written files, so it is never loaded (no unpickling)."""
+    with np.load(filename, allow_pickle=False) as data:
+        u = scipy.sparse.csr_matrix(
+            (data["U_data"], data["U_indices"], data["U_indptr"]), shape=tuple(data["U_shape"])
+        ).tocoo()
+        v = data["Vt"]
+        fov = data["fov_shape"]
+        order = str(data["fov_order"].item())
+        return PMDArray(
+            u, data["R"], data["s"], v, (v.shape[1], int(fov[0]), int(fov[1])), order,
+            data["mean_img"], data["noise_var_img"],
+        )

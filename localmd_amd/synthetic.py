@@ -1,0 +1,81 @@
+"""
+Synthetic calcium-imaging-like movies of the BASELINE shapes:
+
+    Y[t,i,j] = 100 + sum_n A_n(i,j) C_n(t) + 0.5 sin(2 pi t / 1000) ramp(i,j) + N(0,1)
+
+Gaussian footprints (sigma = 3 px, peak 5..20, ~2 sources per 20x20 px), traces = Poisson
+spikes (rate 0.01 / frame) convolved with exp(-t/20).  ``make_movie`` is the NumPy
+generator (tests, CPU baseline); ``make_movie_torch`` evaluates the same formula on a torch
+device in pixel strips so the 10 GB headline movie never exists on the host.
+"""
+import math
+
+import numpy as np
+
+
+def _sources(d1, d2, T, rng, density=2.0 / 400.0):
+    n = max(1, int(round(d1 * d2 * density)))
+    ci = rng.uniform(0, d1, n)
+    cj = rng.uniform(0, d2, n)
+    peak = rng.uniform(5.0, 20.0, n)
+    spikes = (rng.random((n, T)) < 0.01).astype(np.float32)
+    # exp(-t/20) kernel via a first-order recursion
+    decay = math.exp(-1.0 / 20.0)
+    traces = np.empty((n, T), dtype=np.float32)
+    acc = np.zeros(n, dtype=np.float32)
+    for t in range(T):
+        acc = acc * decay + spikes[:, t]
+        traces[:, t] = acc
+    return ci, cj, peak, traces
+
+
+def make_movie(T, d1, d2, seed=0, noise=1.0, dtype=np.float32):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    ci, cj, peak, traces = _sources(d1, d2, T, rng)
+    ii = np.arange(d1, dtype=np.float32)[:, None]
+    jj = np.arange(d2, dtype=np.float32)[None, :]
+    foot = np.empty((len(ci), d1, d2), dtype=np.float32)
+    for n in range(len(ci)):
+        foot[n] = peak[n] * np.exp(-((ii - ci[n]) ** 2 + (jj - cj[n]) ** 2) / (2 * 3.0 ** 2))
+    foot[foot < 1e-3 * peak[:, None, None]] = 0
+    movie = np.tensordot(traces.T, foot, axes=(1, 0))  # (T, d1, d2)
+    ramp = (ii / max(d1 - 1, 1) + jj / max(d2 - 1, 1)).astype(np.float32)
+    slow = (0.5 * np.sin(2 * np.pi * np.arange(T) / 1000.0)).astype(np.float32)
+    movie += slow[:, None, None] * ramp[None]
+    movie += 100.0
+    movie += noise * rng.standard_normal((T, d1, d2), dtype=np.float32)
+    return movie.astype(dtype)
+
+
+def make_movie_torch(T, d1, d2, device, seed=0, noise=1.0, strip=64):
+    """Same model on ``device`` (float32, (T, d1, d2)); sources drawn on host with the same
+    generator as ``make_movie``; noise from torch's device generator."""
+    import torch
+
+    rng = np.random.Generator(np.random.PCG64(seed))
+    ci, cj, peak, traces = _sources(d1, d2, T, rng)
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    tr = torch.from_numpy(traces).to(device)  # (n, T)
+    ci_t = torch.from_numpy(ci.astype(np.float32)).to(device)
+    cj_t = torch.from_numpy(cj.astype(np.float32)).to(device)
+    pk_t = torch.from_numpy(peak.astype(np.float32)).to(device)
+    slow = 0.5 * torch.sin(2 * math.pi * torch.arange(T, device=device, dtype=torch.float32) / 1000.0)
+    jj = torch.arange(d2, device=device, dtype=torch.float32)
+    movie = torch.empty((T, d1, d2), device=device, dtype=torch.float32)
+    for i0 in range(0, d1, strip):
+        i1 = min(d1, i0 + strip)
+        ii = torch.arange(i0, i1, device=device, dtype=torch.float32)
+        near = ((ci_t > i0 - 12) & (ci_t < i1 + 12)).nonzero().flatten()
+        di = ii[None, :, None] - ci_t[near, None, None]
+        dj = jj[None, None, :] - cj_t[near, None, None]
+        foot = pk_t[near, None, None] * torch.exp(-(di * di + dj * dj) / (2 * 3.0 ** 2))
+        foot = torch.where(foot < 1e-3 * pk_t[near, None, None], torch.zeros_like(foot), foot)
+        block = torch.matmul(tr[near].T, foot.reshape(len(near), -1)).reshape(T, i1 - i0, d2)
+        ramp = ii[:, None] / max(d1 - 1, 1) + jj[None, :] / max(d2 - 1, 1)
+        block += slow[:, None, None] * ramp[None]
+        block += 100.0
+        block += noise * torch.randn(block.shape, device=device, dtype=torch.float32, generator=g)
+        movie[:, i0:i1, :] = block
+        del block, foot, di, dj
+    return movie
