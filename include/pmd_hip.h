@@ -1,0 +1,155 @@
+/*
+ * libpmd_hip.so -- C ABI of the MI355X (gfx950) blockwise-PMD hot path.
+ *
+ * The reference (apasarkar/localmd @ 2025-01-31) has no FFI: its hot path is @jit-ed JAX
+ * behind plain Python callables.  Each entry point below replaces the jit region(s) cited
+ * next to it (paths under /root/reference/localmd/); INTEGRATION.md shows the ctypes stub a
+ * maintainer of the reference would add to bind them.
+ *
+ * Conventions
+ *   - every function returns int32: 0 = OK, negative = error; pmd_last_error(ctx) has the text
+ *   - all pointers are DEVICE pointers owned by the caller unless the name ends in _host
+ *   - all work is enqueued on the context's HIP stream; functions that must read a result on
+ *     the host (pmd_orthogonalize, pmd_projected_svd) synchronise that stream themselves
+ *   - scratch memory is a caller-provided workspace; *_workspace_bytes() sizes it
+ *   - one context per (host thread, device); distinct contexts are independent
+ *
+ * Layouts
+ *   movie        Y[t][c]            frames-first, c = i*d2 + j (what the dataset hands over)
+ *   pixel-major  X[c][t]            leading dimension ld = pmd_time_ld(T); zero padded
+ *   tile pixels  pix[tile][q]       q = il + b1*jl (column-major inside the tile, as the
+ *                                   reference's order="F" reshapes), value = FOV pixel c
+ *   tile basis   Ut[tile][comp][q]  64 component rows (rows >= rank are zero), row length
+ *                                   pmd_tile_dpad(b1*b2)
+ *   tile traces  V[tile][comp][t]   64 component rows, leading dimension ldv >= pmd_time_ld(T)
+ */
+#ifndef PMD_HIP_H
+#define PMD_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pmd_ctx pmd_ctx;
+
+int pmd_version(void);
+/* hip_stream: a hipStream_t (0 = the null stream).  The context never owns the stream. */
+int pmd_ctx_create(int device, void* hip_stream, pmd_ctx** out);
+int pmd_ctx_destroy(pmd_ctx* ctx);
+int pmd_ctx_set_stream(pmd_ctx* ctx, void* hip_stream);
+int pmd_ctx_sync(pmd_ctx* ctx);
+const char* pmd_last_error(pmd_ctx* ctx);
+
+/* padded sizes every caller needs to allocate buffers */
+int pmd_tile_dpad(int d);       /* padded pixel count of a d-pixel tile (-1: unsupported)   */
+long pmd_time_ld(long t);       /* leading dimension of a time-contiguous row of t frames   */
+
+/* Gaussian matrices (replaces jax.random.normal: decomposition.py:62,:127,:870; pmd_loader.py:56).
+ * Logical array (stream, index0 + b*index_step), rows x cols, element e = row*cols + col, is
+ * written to out[b*batch_stride + row*ld + col] (transpose=0) or [.. + col*ld + row] (1). */
+int pmd_rng_normal(pmd_ctx* ctx, uint64_t seed, uint32_t stream, uint32_t index0, uint32_t index_step, int batch,
+                   long rows, int cols, int transpose, float* out, long ld, long batch_stride);
+
+/* A1: per-pixel mean and Welch noise sigma (pmd_loader.py:203-291; preprocessing_utils.py:10-40). */
+size_t pmd_stats_workspace_bytes(int T, long D, int frame_const);
+int pmd_stats(pmd_ctx* ctx, const float* movie, int T, long D, int frame_const, int compute_normalizer,
+              float* mean_out, float* std_out, void* ws, size_t ws_bytes);
+
+/* (Y - mean)/std of selected frames, transposed to pixel-major (pmd_loader.py:293-298, :376-377,
+ * :396-397).  frames: device int32[nf] or NULL for frames 0..nf-1.  out: D rows x ld. */
+int pmd_standardize_transpose(pmd_ctx* ctx, const float* movie, long D, const int* frames, int nf, const float* mean,
+                              const float* std, float* out, long ld);
+
+/* A2: background basis = rank-K rSVD of the standardised sample (pmd_loader.py:46-68, :300-314).
+ * xs: pixel-major sample with round_up(D,1024) rows allocated (rows >= D zero). basis_out[c][k]. */
+size_t pmd_background_rsvd_workspace_bytes(long D, int n);
+int pmd_background_rsvd(pmd_ctx* ctx, const float* xs, long D, int n, long ld, int K, uint64_t seed, float* basis_out,
+                        void* ws, size_t ws_bytes);
+
+/* A5: temporal projection B^T X (pmd_loader.py:386) and X - B (B^T X) (:387). */
+size_t pmd_bg_project_workspace_bytes(long D, int T);
+int pmd_bg_project(pmd_ctx* ctx, const float* xs, long D, int T, long ld, const float* basis, int K, float* pj_out,
+                   long ldp, void* ws, size_t ws_bytes);
+int pmd_bg_filter(pmd_ctx* ctx, const float* xs, float* xf_out, long D, int nf, long ld, const float* basis, int K,
+                  const float* pj, long ldp);
+/* pixel_weighting (decomposition.py:717-718) */
+int pmd_scale_rows(pmd_ctx* ctx, float* x, long D, int nf, long ld, const float* w);
+
+/* A4: threshold simulation (decomposition.py:76-131, :147-181).  stats_out[iter][0..1] =
+ * (spatial, temporal) roughness of the rank-1 rSVD of an N(0,1) tile; the percentile is host work. */
+size_t pmd_threshold_sim_workspace_bytes(int b1, int b2, int t, int iters);
+int pmd_threshold_sim(pmd_ctx* ctx, int b1, int b2, int t, int iters, uint64_t seed, float* stats_out, void* ws,
+                      size_t ws_bytes);
+
+/* A6-A12: per-tile decomposition, one window (decomposition.py:235-330 single_block_md,
+ * evaluation.py:84-222, decomposition.py:501-523).  Omega of tile b is logical array
+ * (PMD_STREAM_TILE_OMEGA = 4, omega_index0 + b*omega_index_step).
+ * pool_q[P][pool_max]: local pixels of pooling window p (-1 pads); pool_idx[q]: window of pixel q;
+ * pool_w[q] = 1/|window|.  Outputs: Ut_out[n][64][dpad], V_out[n][64][ldv] (= sigma*V rows),
+ * stats_out[n][64][2], good_out/keep_out[n][64], ranks_out[n], lam_out[n][64] (sigma^2, may be NULL). */
+size_t pmd_tiles_workspace_bytes(int n_tiles, int b1, int b2, int P, int r, int a, int t_crop, long ldv);
+int pmd_tiles_decompose(pmd_ctx* ctx, const float* xf, long ldx, int t_crop, const int* tile_pix, int n_tiles, int b1,
+                        int b2, const int* pool_q, int pool_max, int P, const int* pool_idx, const float* pool_w, int r,
+                        int a, float thr_s, float thr_t, int max_fail, uint64_t seed, uint32_t omega_index0,
+                        uint32_t omega_index_step, float* Ut_out, float* V_out, long ldv, float* stats_out,
+                        int* good_out, int* keep_out, int* ranks_out, double* lam_out, void* ws, size_t ws_bytes);
+
+/* A13: weight and normalise tile bases: Uw = Ut * w[q] / cumw[pix]  (decomposition.py:812-853). */
+int pmd_weight_tiles(pmd_ctx* ctx, const float* Ut, int dpad, const int* tile_pix, int d, const float* w,
+                     const float* cumw, const int* ranks, float* Uw_out, int n_tiles);
+
+/* A12/A16: Out[tile] = A[tile] X[tile pixels]  (get_temporal_projector decomposition.py:390-407;
+ * the sparse product of pmd_loader.py:411).  A[tile][64][dpad]; Out[tile][64][ldo]. */
+int pmd_tiles_project(pmd_ctx* ctx, const float* x, long ldx, int T, const int* tile_pix, int n_tiles, int d,
+                      const float* A, int dpad, float* Out, long ldo, int slices);
+/* Z[col_off[tile] + c][t] = Out[tile][c][t], c < ranks[tile] */
+int pmd_compact_rows(pmd_ctx* ctx, const float* Out, long ldo, const int* col_off, const int* ranks, int T, float* Z,
+                     long ldz, int n_tiles);
+
+/* A15: G = U^T U for the block-sparse U (decomposition.py:974); pairs[p] = (tile a, tile b, i0, i1,
+ * j0, j1) overlap rectangles, origins[tile] = (k, j).  G is (Rt+K) x (Rt+K), row-major, ldg. */
+int pmd_gram_u(pmd_ctx* ctx, const float* Uw, int dpad, int b1, int b2, const int* tile_pix, const int* pairs,
+               int n_pairs, const int* origins, const int* col_off, const int* ranks, int n_tiles, int Rt,
+               const float* basis, long D, int K, float* G, long ldg);
+/* A15: P with (U P)^T (U P) = I (decomposition.py:976-999, only_left=True).  M = right matrix
+ * (R x m, NULL = identity, then m = R).  G is overwritten.  *rprime_host = columns kept. */
+size_t pmd_orthogonalize_workspace_bytes(int R, int m, int has_m);
+int pmd_orthogonalize(pmd_ctx* ctx, float* G, int R, const float* M, int m, long ldm, float* P_out, long ldp,
+                      int* rprime_host, void* ws, size_t ws_bytes);
+/* A17: projected_svd (decomposition.py:1013-1137).  V: n1 x n2.  nk = min(n1, n2). */
+size_t pmd_projected_svd_workspace_bytes(int rows_p, int n1, int n2);
+int pmd_projected_svd(pmd_ctx* ctx, const float* P, int rows_p, long ldp, const float* V, int n1, int n2, long ldv,
+                      float* R_out, long ldr, float* s_out, float* Vt_out, long ldvt, void* ws, size_t ws_bytes);
+/* row-major C = alpha op(A) op(B) + beta C (the jnp.matmul calls of decomposition.py:873, :982, :993,
+ * :1006; pmd_loader.py:412) */
+int pmd_gemm(pmd_ctx* ctx, int transA, int transB, int m, int n, int k, float alpha, const float* A, long lda,
+             const float* B, long ldb, float beta, float* C, long ldc);
+
+/* ---- kernel-level entry points (used by the parity tests; same kernels as above) ---------- */
+int pmdk_tile_atx(pmd_ctx* ctx, const float* X, long ldx, const int* pix, int pix_stride, long row0_stride, int d,
+                  const float* A, long a_tile_stride, int a_ld, float* Out, long out_tile_stride, long ldo, int n_tiles,
+                  int T, int slices);
+int pmdk_tile_xbt(pmd_ctx* ctx, const float* X, long ldx, const int* pix, int pix_stride, long row0_stride, int d,
+                  const float* B, long b_tile_stride, long ldb, float* S, long s_tile_stride, long s_slice_stride,
+                  int s_ld, int n_tiles, int T, int slices);
+int pmdk_tile_gram(pmd_ctx* ctx, const float* In, long tile_stride, long ld, int len, int n_tiles, int slices,
+                   double* G);
+int pmdk_tile_rowmix(pmd_ctx* ctx, const float* In, long in_tile_stride, long ld_in, const double* N,
+                     long n_tile_stride, int n_in, int n_out, float* Out, long out_tile_stride, long ld_out, int len,
+                     int n_tiles);
+int pmdk_small_qr(pmd_ctx* ctx, const float* Yt, long y_tile_stride, int y_ld, int P, int l, float* Qt,
+                  long q_tile_stride, int q_ld, int n_tiles);
+int pmdk_small_eig(pmd_ctx* ctx, const double* G, int slices, int n, int mode, double tol, double* Nout,
+                   double* lam_out, int n_tiles);
+int pmdk_tile_pool_bin(pmd_ctx* ctx, const float* X, long ldx, const int* pix, int n_tiles, int d, const int* pool_q,
+                       int pool_max, int P, int a, int nbins, float* abar, long ld_ab, long tile_stride);
+int pmdk_roughness(pmd_ctx* ctx, const float* Ut, long u_tile_stride, int u_ld, int b1, int b2, const float* V,
+                   long v_tile_stride, long v_ld, int T, int r, float* stats, int n_tiles);
+int pmdk_syevd(pmd_ctx* ctx, int n, float* A, long lda, float* w, float* work, int* info);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,219 @@
+// extern "C" surface of libpmd_hip.so (declared in include/pmd_hip.h).
+#include "pmd_internal.h"
+#include "../../include/pmd_hip.h"
+
+#define CTX_CHECK(ctx) \
+  if (!(ctx)) return PMD_ERR_ARG;
+
+extern "C" {
+
+int pmd_version(void) { return 1; }
+
+int pmd_ctx_create(int device, void* hip_stream, pmd_ctx** out) {
+  if (!out) return PMD_ERR_ARG;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return PMD_ERR_HIP;
+  if (hipSetDevice(device) != hipSuccess) return PMD_ERR_HIP;
+  pmd_ctx* ctx = new pmd_ctx();
+  ctx->device = device;
+  ctx->stream = (hipStream_t)hip_stream;
+  ctx->tables = nullptr;
+  ctx->blas = nullptr;
+  ctx->err[0] = 0;
+  if (rocblas_create_handle(&ctx->blas) != rocblas_status_success) { delete ctx; return PMD_ERR_BLAS; }
+  rocblas_set_stream(ctx->blas, ctx->stream);
+  rocblas_set_pointer_mode(ctx->blas, rocblas_pointer_mode_host);
+  if (pmd_init_tables(ctx) != PMD_OK) { rocblas_destroy_handle(ctx->blas); delete ctx; return PMD_ERR_HIP; }
+  *out = ctx;
+  return PMD_OK;
+}
+
+int pmd_ctx_destroy(pmd_ctx* ctx) {
+  CTX_CHECK(ctx);
+  hipSetDevice(ctx->device);
+  if (ctx->tables) hipFree(ctx->tables);
+  if (ctx->blas) rocblas_destroy_handle(ctx->blas);
+  delete ctx;
+  return PMD_OK;
+}
+
+int pmd_ctx_set_stream(pmd_ctx* ctx, void* hip_stream) {
+  CTX_CHECK(ctx);
+  ctx->stream = (hipStream_t)hip_stream;
+  rocblas_set_stream(ctx->blas, ctx->stream);
+  return PMD_OK;
+}
+
+int pmd_ctx_sync(pmd_ctx* ctx) {
+  CTX_CHECK(ctx);
+  PMD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return PMD_OK;
+}
+
+const char* pmd_last_error(pmd_ctx* ctx) { return ctx ? ctx->err : "null context"; }
+
+int pmd_rng_normal(pmd_ctx* ctx, uint64_t seed, uint32_t stream, uint32_t index0, uint32_t index_step, int batch,
+                   long rows, int cols, int transpose, float* out, long ld, long batch_stride) {
+  CTX_CHECK(ctx);
+  for (int b0 = 0; b0 < batch; b0 += 32768) {
+    const int bn = (batch - b0 < 32768) ? batch - b0 : 32768;
+    int rc = pmd_launch_rng(ctx, seed, stream, index0 + (uint32_t)b0 * index_step, index_step, bn, rows, cols, transpose,
+                            out + (long)b0 * batch_stride, ld, batch_stride);
+    if (rc != PMD_OK) return rc;
+  }
+  return PMD_OK;
+}
+
+int pmd_stats(pmd_ctx* ctx, const float* movie, int T, long D, int frame_const, int compute_normalizer, float* mean_out,
+              float* std_out, void* ws, size_t ws_bytes) {
+  CTX_CHECK(ctx);
+  return pmd_launch_stats(ctx, movie, T, D, frame_const, compute_normalizer, mean_out, std_out, ws, ws_bytes);
+}
+
+int pmd_standardize_transpose(pmd_ctx* ctx, const float* movie, long D, const int* frames, int nf, const float* mean,
+                              const float* std, float* out, long ld) {
+  CTX_CHECK(ctx);
+  return pmd_launch_standardize_transpose(ctx, movie, D, frames, nf, mean, std, out, ld);
+}
+
+size_t pmd_background_rsvd_workspace_bytes(long D, int n) { return pmd_bg_workspace_bytes_impl(D, n); }
+int pmd_background_rsvd(pmd_ctx* ctx, const float* xs, long D, int n, long ld, int K, uint64_t seed, float* basis_out,
+                        void* ws, size_t ws_bytes) {
+  CTX_CHECK(ctx);
+  return pmd_background_rsvd_impl(ctx, xs, D, n, ld, K, seed, basis_out, ws, ws_bytes);
+}
+
+size_t pmd_bg_project_workspace_bytes(long D, int T) { return pmd_bg_project_workspace_bytes_impl(D, T); }
+int pmd_bg_project(pmd_ctx* ctx, const float* xs, long D, int T, long ld, const float* basis, int K, float* pj_out,
+                   long ldp, void* ws, size_t ws_bytes) {
+  CTX_CHECK(ctx);
+  return pmd_bg_project_impl(ctx, xs, D, T, ld, basis, K, pj_out, ldp, ws, ws_bytes);
+}
+int pmd_bg_filter(pmd_ctx* ctx, const float* xs, float* xf_out, long D, int nf, long ld, const float* basis, int K,
+                  const float* pj, long ldp) {
+  CTX_CHECK(ctx);
+  return pmd_launch_filter(ctx, xs, xf_out, D, nf, ld, basis, K, pj, ldp);
+}
+int pmd_scale_rows(pmd_ctx* ctx, float* x, long D, int nf, long ld, const float* w) {
+  CTX_CHECK(ctx);
+  return pmd_launch_scale_rows(ctx, x, D, nf, ld, w);
+}
+
+size_t pmd_threshold_sim_workspace_bytes(int b1, int b2, int t, int iters) {
+  return pmd_sim_workspace_bytes_impl(b1 * b2, t, iters);
+}
+int pmd_threshold_sim(pmd_ctx* ctx, int b1, int b2, int t, int iters, uint64_t seed, float* stats_out, void* ws,
+                      size_t ws_bytes) {
+  CTX_CHECK(ctx);
+  return pmd_threshold_sim_impl(ctx, b1, b2, t, iters, seed, stats_out, ws, ws_bytes);
+}
+
+size_t pmd_tiles_workspace_bytes(int n_tiles, int b1, int b2, int P, int r, int a, int t_crop, long ldv) {
+  return pmd_tiles_workspace_bytes_impl(n_tiles, b1 * b2, P, r, a, t_crop, ldv);
+}
+int pmd_tiles_decompose(pmd_ctx* ctx, const float* xf, long ldx, int t_crop, const int* tile_pix, int n_tiles, int b1,
+                        int b2, const int* pool_q, int pool_max, int P, const int* pool_idx, const float* pool_w, int r,
+                        int a, float thr_s, float thr_t, int max_fail, uint64_t seed, uint32_t omega_index0,
+                        uint32_t omega_index_step, float* Ut_out, float* V_out, long ldv, float* stats_out,
+                        int* good_out, int* keep_out, int* ranks_out, double* lam_out, void* ws, size_t ws_bytes) {
+  CTX_CHECK(ctx);
+  return pmd_tiles_decompose_impl(ctx, xf, ldx, t_crop, tile_pix, n_tiles, b1, b2, pool_q, pool_max, P, pool_idx,
+                                  pool_w, r, a, thr_s, thr_t, max_fail, seed, omega_index0, omega_index_step, Ut_out,
+                                  V_out, ldv, stats_out, good_out, keep_out, ranks_out, lam_out, ws, ws_bytes);
+}
+
+int pmd_weight_tiles(pmd_ctx* ctx, const float* Ut, int dpad, const int* tile_pix, int d, const float* w,
+                     const float* cumw, const int* ranks, float* Uw_out, int n_tiles) {
+  CTX_CHECK(ctx);
+  return pmd_launch_weight_tiles(ctx, Ut, dpad, tile_pix, d, w, cumw, ranks, Uw_out, n_tiles);
+}
+
+int pmd_tiles_project(pmd_ctx* ctx, const float* x, long ldx, int T, const int* tile_pix, int n_tiles, int d,
+                      const float* A, int dpad, float* Out, long ldo, int slices) {
+  CTX_CHECK(ctx);
+  return pmd_launch_tile_atx(ctx, x, ldx, tile_pix, d, 0, d, A, 64L * dpad, dpad, Out, 64L * ldo, ldo, n_tiles, T, slices);
+}
+
+int pmd_compact_rows(pmd_ctx* ctx, const float* Out, long ldo, const int* col_off, const int* ranks, int T, float* Z,
+                     long ldz, int n_tiles) {
+  CTX_CHECK(ctx);
+  return pmd_launch_compact_rows(ctx, Out, 64L * ldo, ldo, col_off, ranks, T, Z, ldz, n_tiles);
+}
+
+int pmd_gram_u(pmd_ctx* ctx, const float* Uw, int dpad, int b1, int b2, const int* tile_pix, const int* pairs,
+               int n_pairs, const int* origins, const int* col_off, const int* ranks, int n_tiles, int Rt,
+               const float* basis, long D, int K, float* G, long ldg) {
+  CTX_CHECK(ctx);
+  return pmd_gram_u_impl(ctx, Uw, dpad, b1, b2, tile_pix, pairs, n_pairs, origins, col_off, ranks, n_tiles, Rt, basis, D,
+                         K, G, ldg);
+}
+
+size_t pmd_orthogonalize_workspace_bytes(int R, int m, int has_m) { return pmd_orthogonalize_workspace_bytes_impl(R, m, has_m); }
+int pmd_orthogonalize(pmd_ctx* ctx, float* G, int R, const float* M, int m, long ldm, float* P_out, long ldp,
+                      int* rprime_host, void* ws, size_t ws_bytes) {
+  CTX_CHECK(ctx);
+  return pmd_orthogonalize_impl(ctx, G, R, M, m, ldm, P_out, ldp, rprime_host, ws, ws_bytes);
+}
+
+size_t pmd_projected_svd_workspace_bytes(int rows_p, int n1, int n2) { return pmd_projected_svd_workspace_bytes_impl(rows_p, n1, n2); }
+int pmd_projected_svd(pmd_ctx* ctx, const float* P, int rows_p, long ldp, const float* V, int n1, int n2, long ldv,
+                      float* R_out, long ldr, float* s_out, float* Vt_out, long ldvt, void* ws, size_t ws_bytes) {
+  CTX_CHECK(ctx);
+  return pmd_projected_svd_impl(ctx, P, rows_p, ldp, V, n1, n2, ldv, R_out, ldr, s_out, Vt_out, ldvt, ws, ws_bytes);
+}
+
+int pmd_gemm(pmd_ctx* ctx, int transA, int transB, int m, int n, int k, float alpha, const float* A, long lda,
+             const float* B, long ldb, float beta, float* C, long ldc) {
+  CTX_CHECK(ctx);
+  return pmd_gemm_rm(ctx, transA, transB, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc);
+}
+
+// ---- kernel-level entry points ---------------------------------------------------------------
+int pmdk_tile_atx(pmd_ctx* ctx, const float* X, long ldx, const int* pix, int pix_stride, long row0_stride, int d,
+                  const float* A, long a_tile_stride, int a_ld, float* Out, long out_tile_stride, long ldo, int n_tiles,
+                  int T, int slices) {
+  CTX_CHECK(ctx);
+  return pmd_launch_tile_atx(ctx, X, ldx, pix, pix_stride, row0_stride, d, A, a_tile_stride, a_ld, Out, out_tile_stride, ldo, n_tiles, T, slices);
+}
+int pmdk_tile_xbt(pmd_ctx* ctx, const float* X, long ldx, const int* pix, int pix_stride, long row0_stride, int d,
+                  const float* B, long b_tile_stride, long ldb, float* S, long s_tile_stride, long s_slice_stride,
+                  int s_ld, int n_tiles, int T, int slices) {
+  CTX_CHECK(ctx);
+  return pmd_launch_tile_xbt(ctx, X, ldx, pix, pix_stride, row0_stride, d, B, b_tile_stride, ldb, S, s_tile_stride, s_slice_stride, s_ld, n_tiles, T, slices);
+}
+int pmdk_tile_gram(pmd_ctx* ctx, const float* In, long tile_stride, long ld, int len, int n_tiles, int slices, double* G) {
+  CTX_CHECK(ctx);
+  return pmd_launch_tile_gram(ctx, In, tile_stride, ld, len, n_tiles, slices, G);
+}
+int pmdk_tile_rowmix(pmd_ctx* ctx, const float* In, long in_tile_stride, long ld_in, const double* N, long n_tile_stride,
+                     int n_in, int n_out, float* Out, long out_tile_stride, long ld_out, int len, int n_tiles) {
+  CTX_CHECK(ctx);
+  return pmd_launch_tile_rowmix(ctx, In, in_tile_stride, ld_in, N, n_tile_stride, n_in, n_out, Out, out_tile_stride, ld_out, len, n_tiles);
+}
+int pmdk_small_qr(pmd_ctx* ctx, const float* Yt, long y_tile_stride, int y_ld, int P, int l, float* Qt, long q_tile_stride,
+                  int q_ld, int n_tiles) {
+  CTX_CHECK(ctx);
+  return pmd_launch_small_qr(ctx, Yt, y_tile_stride, y_ld, P, l, Qt, q_tile_stride, q_ld, n_tiles);
+}
+int pmdk_small_eig(pmd_ctx* ctx, const double* G, int slices, int n, int mode, double tol, double* Nout, double* lam_out,
+                   int n_tiles) {
+  CTX_CHECK(ctx);
+  return pmd_launch_small_eig(ctx, G, slices, n, mode, tol, Nout, lam_out, n_tiles);
+}
+int pmdk_tile_pool_bin(pmd_ctx* ctx, const float* X, long ldx, const int* pix, int n_tiles, int d, const int* pool_q,
+                       int pool_max, int P, int a, int nbins, float* abar, long ld_ab, long tile_stride) {
+  CTX_CHECK(ctx);
+  return pmd_launch_tile_pool_bin(ctx, X, ldx, pix, n_tiles, d, pool_q, pool_max, P, a, nbins, abar, ld_ab, tile_stride);
+}
+int pmdk_roughness(pmd_ctx* ctx, const float* Ut, long u_tile_stride, int u_ld, int b1, int b2, const float* V,
+                   long v_tile_stride, long v_ld, int T, int r, float* stats, int n_tiles) {
+  CTX_CHECK(ctx);
+  return pmd_launch_stats_roughness(ctx, Ut, u_tile_stride, u_ld, b1, b2, V, v_tile_stride, v_ld, T, r, stats, n_tiles);
+}
+int pmdk_syevd(pmd_ctx* ctx, int n, float* A, long lda, float* w, float* work, int* info) {
+  CTX_CHECK(ctx);
+  return pmd_syevd(ctx, n, A, lda, w, work, info);
+}
+
+}  // extern "C"

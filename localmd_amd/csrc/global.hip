@@ -1,0 +1,433 @@
+// Global recombination: U^T U, orthogonalising mixing matrix P, V projection helpers and the
+// projected SVD (decomposition.py:912-1137, pmd_loader.py:316-346, :392-414).
+// Dense fp32 GEMMs go to rocBLAS and the dense symmetric eigenproblem to rocSOLVER (ssyevd);
+// everything else is hand-written.  Matrices are row-major; the rocBLAS calls use the usual
+// operand swap (C^T = B^T A^T).
+#include "pmd_internal.h"
+#include <rocsolver/rocsolver.h>
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#define RUN(call)                 \
+  do {                            \
+    int rc__ = (call);            \
+    if (rc__ != PMD_OK) return rc__; \
+  } while (0)
+
+#define PMD_BLAS(ctx, call)                                                     \
+  do {                                                                          \
+    rocblas_status s__ = (call);                                                \
+    if (s__ != rocblas_status_success) return pmd_fail(ctx, PMD_ERR_BLAS, #call, rocblas_status_to_string(s__)); \
+  } while (0)
+
+// row-major C(m x n) = alpha * op(A) * op(B) + beta * C
+int pmd_gemm_rm(pmd_ctx* ctx, int transA, int transB, int m, int n, int k, float alpha, const float* A, long lda,
+                const float* B, long ldb, float beta, float* C, long ldc) {
+  if (m <= 0 || n <= 0) return PMD_OK;
+  PMD_BLAS(ctx, rocblas_sgemm(ctx->blas, transB ? rocblas_operation_transpose : rocblas_operation_none,
+                              transA ? rocblas_operation_transpose : rocblas_operation_none, n, m, k, &alpha, B,
+                              (rocblas_int)ldb, A, (rocblas_int)lda, &beta, C, (rocblas_int)ldc));
+  return PMD_OK;
+}
+
+// symmetric eigendecomposition, ascending eigenvalues; on exit row j of A is eigenvector j.
+// work: n floats, info: device int.
+int pmd_syevd(pmd_ctx* ctx, int n, float* A, long lda, float* w, float* work, int* info) {
+  PMD_BLAS(ctx, rocsolver_ssyevd(ctx->blas, rocblas_evect_original, rocblas_fill_upper, n, A, (rocblas_int)lda, w, work, info));
+  return PMD_OK;
+}
+
+// ---------------------------------------------------------------- weighted tile bases ------
+// Uw[tile][c][q] = Ut[tile][c][q] * w[q] / cumw[pix[tile][q]] for c < ranks[tile], else 0
+// (decomposition.py:812-816, :847-853).
+__global__ void weight_tiles_kernel(const float* __restrict__ Ut, long tile_stride, int ld, const int* __restrict__ pix,
+                                    int d, const float* __restrict__ w, const float* __restrict__ cumw,
+                                    const int* __restrict__ ranks, float* __restrict__ Uw) {
+  const int tile = blockIdx.y;
+  const int rk = ranks[tile];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < PMD_RPAD * d; i += gridDim.x * blockDim.x) {
+    const int c = i / d, q = i - c * d;
+    float v = 0.f;
+    if (c < rk) v = Ut[(long)tile * tile_stride + (long)c * ld + q] * w[q] / cumw[pix[(long)tile * d + q]];
+    Uw[(long)tile * tile_stride + (long)c * ld + q] = v;
+  }
+}
+
+int pmd_launch_weight_tiles(pmd_ctx* ctx, const float* Ut, int dpad, const int* pix, int d, const float* w,
+                            const float* cumw, const int* ranks, float* Uw, int n_tiles) {
+  for (int t0 = 0; t0 < n_tiles; t0 += 32768) {
+    const int tn = (n_tiles - t0 < 32768) ? n_tiles - t0 : 32768;
+    hipLaunchKernelGGL(weight_tiles_kernel, dim3(32, tn), dim3(256), 0, ctx->stream, Ut + (long)t0 * 64 * dpad,
+                       64L * dpad, dpad, pix + (long)t0 * d, d, w, cumw, ranks + t0, Uw + (long)t0 * 64 * dpad);
+    PMD_LAUNCH_CHECK(ctx, "weight_tiles_kernel");
+  }
+  return PMD_OK;
+}
+
+// Z[col_off[tile] + c][t] = Out[tile][c][t], c < ranks[tile]
+__global__ void compact_rows_kernel(const float* __restrict__ Out, long tile_stride, long ldo,
+                                    const int* __restrict__ col_off, const int* __restrict__ ranks, int T,
+                                    float* __restrict__ Z, long ldz) {
+  const int tile = blockIdx.y;
+  const int rk = ranks[tile];
+  const long off = col_off[tile];
+  for (int c = 0; c < rk; ++c)
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < T; t += gridDim.x * blockDim.x)
+      Z[(off + c) * ldz + t] = Out[(long)tile * tile_stride + (long)c * ldo + t];
+}
+
+int pmd_launch_compact_rows(pmd_ctx* ctx, const float* Out, long tile_stride, long ldo, const int* col_off,
+                            const int* ranks, int T, float* Z, long ldz, int n_tiles) {
+  for (int t0 = 0; t0 < n_tiles; t0 += 32768) {
+    const int tn = (n_tiles - t0 < 32768) ? n_tiles - t0 : 32768;
+    hipLaunchKernelGGL(compact_rows_kernel, dim3(16, tn), dim3(256), 0, ctx->stream, Out + (long)t0 * tile_stride,
+                       tile_stride, ldo, col_off + t0, ranks + t0, T, Z, ldz);
+    PMD_LAUNCH_CHECK(ctx, "compact_rows_kernel");
+  }
+  return PMD_OK;
+}
+
+// ---------------------------------------------------------------- G = U^T U ----------------
+// pairs[p] = (tile a, tile b, i0, i1, j0, j1): overlap rectangle in FOV coordinates.
+// origins[tile] = (k, j).  Writes G[off_a + c][off_b + c'] and its transpose.
+__global__ __launch_bounds__(256) void gram_pairs_kernel(const float* __restrict__ Uw, int dpad, int b1,
+                                                         const int* __restrict__ pairs, const int* __restrict__ origins,
+                                                         const int* __restrict__ col_off, const int* __restrict__ ranks,
+                                                         float* __restrict__ G, long ldg) {
+  __shared__ float ua[64][65];
+  __shared__ float ub[64][65];
+  const int* pr = pairs + (long)blockIdx.x * 6;
+  const int ta = pr[0], tb = pr[1], i0 = pr[2], i1 = pr[3], j0 = pr[4], j1 = pr[5];
+  const int ra = ranks[ta], rb = ranks[tb];
+  if (ra == 0 || rb == 0) return;
+  const int ka = origins[2 * ta], ja = origins[2 * ta + 1], kb = origins[2 * tb], jb = origins[2 * tb + 1];
+  const int h = i1 - i0, npix = h * (j1 - j0);
+  const int ti = threadIdx.x >> 4, tj = threadIdx.x & 15;
+  double acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+  const float* pa = Uw + (long)ta * 64 * dpad;
+  const float* pb = Uw + (long)tb * 64 * dpad;
+  for (int p0 = 0; p0 < npix; p0 += 64) {
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+      const int c = i >> 6, pl = i & 63;
+      const int p = p0 + pl;
+      float va = 0.f, vb = 0.f;
+      if (p < npix) {
+        const int jj = p / h, ii = p - jj * h;
+        const int gi = i0 + ii, gj = j0 + jj;
+        if (c < ra) va = pa[(long)c * dpad + (gi - ka) + b1 * (gj - ja)];
+        if (c < rb) vb = pb[(long)c * dpad + (gi - kb) + b1 * (gj - jb)];
+      }
+      ua[c][pl] = va;
+      ub[c][pl] = vb;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int pl = 0; pl < 64; ++pl) {
+      double av[4], bv[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) { av[a] = (double)ua[4 * ti + a][pl]; bv[a] = (double)ub[4 * tj + a][pl]; }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = fma(av[a], bv[b], acc[a][b]);
+    }
+    __syncthreads();
+  }
+  const long oa = col_off[ta], ob = col_off[tb];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int c = 4 * ti + a, cp = 4 * tj + b;
+      if (c < ra && cp < rb) {
+        const float v = (float)acc[a][b];
+        G[(oa + c) * ldg + ob + cp] = v;
+        G[(ob + cp) * ldg + oa + c] = v;
+      }
+    }
+}
+
+// tile x background block: G[off + c][Rt + k] = sum_q Uw[tile][c][q] * basis[pix[q]][k]
+__global__ __launch_bounds__(256) void gram_bg_kernel(const float* __restrict__ Uw, int dpad, int d,
+                                                      const int* __restrict__ pix, const float* __restrict__ basis,
+                                                      int K, const int* __restrict__ col_off,
+                                                      const int* __restrict__ ranks, int Rt, float* __restrict__ G,
+                                                      long ldg) {
+  const int tile = blockIdx.x;
+  const int rk = ranks[tile];
+  const long off = col_off[tile];
+  for (int i = threadIdx.x; i < rk * K; i += 256) {
+    const int c = i / K, k = i - c * K;
+    double s = 0.0;
+    for (int q = 0; q < d; ++q)
+      s += (double)Uw[(long)tile * 64 * dpad + (long)c * dpad + q] * (double)basis[(long)pix[(long)tile * d + q] * K + k];
+    G[(off + c) * ldg + Rt + k] = (float)s;
+    G[(long)(Rt + k) * ldg + off + c] = (float)s;
+  }
+}
+
+// background x background: one workgroup per entry
+__global__ __launch_bounds__(256) void gram_bgbg_kernel(const float* __restrict__ basis, long D, int K, int Rt,
+                                                        float* __restrict__ G, long ldg) {
+  __shared__ double red[256];
+  const int k1 = blockIdx.x, k2 = blockIdx.y;
+  if (k2 < k1) return;
+  double s = 0.0;
+  for (long c = threadIdx.x; c < D; c += 256) s += (double)basis[c * K + k1] * (double)basis[c * K + k2];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    G[(long)(Rt + k1) * ldg + Rt + k2] = (float)red[0];
+    G[(long)(Rt + k2) * ldg + Rt + k1] = (float)red[0];
+  }
+}
+
+int pmd_gram_u_impl(pmd_ctx* ctx, const float* Uw, int dpad, int b1, int b2, const int* pix, const int* pairs,
+                    int n_pairs, const int* origins, const int* col_off, const int* ranks, int n_tiles, int Rt,
+                    const float* basis, long D, int K, float* G, long ldg) {
+  const long R = Rt + K;
+  PMD_HIP(ctx, hipMemsetAsync(G, 0, (size_t)R * ldg * sizeof(float), ctx->stream));
+  if (n_pairs > 0) {
+    hipLaunchKernelGGL(gram_pairs_kernel, dim3(n_pairs), dim3(256), 0, ctx->stream, Uw, dpad, b1, pairs, origins,
+                       col_off, ranks, G, ldg);
+    PMD_LAUNCH_CHECK(ctx, "gram_pairs_kernel");
+  }
+  if (K > 0) {
+    hipLaunchKernelGGL(gram_bg_kernel, dim3(n_tiles), dim3(256), 0, ctx->stream, Uw, dpad, b1 * b2, pix, basis, K,
+                       col_off, ranks, Rt, G, ldg);
+    PMD_LAUNCH_CHECK(ctx, "gram_bg_kernel");
+    hipLaunchKernelGGL(gram_bgbg_kernel, dim3(K, K), dim3(256), 0, ctx->stream, basis, D, K, Rt, G, ldg);
+    PMD_LAUNCH_CHECK(ctx, "gram_bgbg_kernel");
+  }
+  return PMD_OK;
+}
+
+// ---------------------------------------------------------------- helpers for eigen output -
+// dst[c][x] = src[perm[c]][x] * scale[c]   (row gather of the eigenvector matrix)
+__global__ void gather_rows_scale_kernel(const float* __restrict__ src, long lds_, const int* __restrict__ perm,
+                                         const float* __restrict__ scale, int ncols, float* __restrict__ dst, long ldd) {
+  const int c = blockIdx.y;
+  const float s = scale[c];
+  const long r = perm[c];
+  for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < ncols; x += gridDim.x * blockDim.x)
+    dst[(long)c * ldd + x] = src[r * lds_ + x] * s;
+}
+
+__global__ void transpose_kernel(const float* __restrict__ src, long lds_, int rows, int cols, float* __restrict__ dst,
+                                 long ldd) {
+  __shared__ float t[32][33];
+  const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int r = ty; r < 32; r += 8)
+    if (y0 + r < rows && x0 + tx < cols) t[r][tx] = src[(long)(y0 + r) * lds_ + x0 + tx];
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8)
+    if (x0 + r < cols && y0 + tx < rows) dst[(long)(x0 + r) * ldd + y0 + tx] = t[tx][r];
+}
+
+__global__ void scale_rows2_kernel(float* __restrict__ x, long ld, int ncols, const float* __restrict__ scale) {
+  const float s = scale[blockIdx.y];
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < ncols; c += gridDim.x * blockDim.x) x[(long)blockIdx.y * ld + c] *= s;
+}
+
+__global__ void scale_cols_kernel(float* __restrict__ x, long ld, int ncols, const float* __restrict__ scale) {
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < ncols; c += gridDim.x * blockDim.x) x[(long)blockIdx.y * ld + c] *= scale[c];
+}
+
+static int launch_gather_rows(pmd_ctx* ctx, const float* src, long lds_, const int* perm, const float* scale, int nrows,
+                              int ncols, float* dst, long ldd) {
+  for (int r0 = 0; r0 < nrows; r0 += 32768) {
+    const int rn = (nrows - r0 < 32768) ? nrows - r0 : 32768;
+    hipLaunchKernelGGL(gather_rows_scale_kernel, dim3(8, rn), dim3(256), 0, ctx->stream, src, lds_, perm + r0,
+                       scale + r0, ncols, dst + (long)r0 * ldd, ldd);
+    PMD_LAUNCH_CHECK(ctx, "gather_rows_scale_kernel");
+  }
+  return PMD_OK;
+}
+
+static int launch_transpose(pmd_ctx* ctx, const float* src, long lds_, int rows, int cols, float* dst, long ldd) {
+  hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, ctx->stream, src, lds_,
+                     rows, cols, dst, ldd);
+  PMD_LAUNCH_CHECK(ctx, "transpose_kernel");
+  return PMD_OK;
+}
+
+// ---------------------------------------------------------------- A15 ----------------------
+// compute_lowrank_factorized_svd(only_left=True), decomposition.py:974-999.
+// G: R x R (overwritten).  M: R x m right matrix (row-major, ldm) or NULL for the identity
+// (reference: right_mat = v if R > v.shape[1] else eye(R)).  P_out: R x R' (ldp >= m).
+// Host sync: the eigenvalues come back to count R' (reference: good_components = eig_vals > 0).
+size_t pmd_orthogonalize_workspace_bytes_impl(int R, int m, int has_m) {
+  size_t b = 0;
+  b += (size_t)m * sizeof(float) * 4 + (size_t)m * sizeof(int) + 4096;  // w, work, scale, perm, info
+  if (has_m) b += (size_t)R * m * sizeof(float) + (size_t)m * m * sizeof(float);  // GM, C
+  b += (size_t)m * m * sizeof(float);                                             // Et
+  return b + 8192;
+}
+
+int pmd_orthogonalize_impl(pmd_ctx* ctx, float* G, int R, const float* M, int m, long ldm, float* P_out, long ldp,
+                           int* rprime_out, void* ws, size_t ws_bytes) {
+  pmd_arena ar(ws, ws_bytes);
+  float* w = ar.take_n<float>(m);
+  float* work = ar.take_n<float>(m);
+  float* scale = ar.take_n<float>(m);
+  int* perm = ar.take_n<int>(m);
+  int* info = ar.take_n<int>(4);
+  float* C = nullptr;
+  float* GM = nullptr;
+  if (M) {
+    GM = ar.take_n<float>((size_t)R * m);
+    C = ar.take_n<float>((size_t)m * m);
+  } else {
+    if (m != R) return pmd_fail(ctx, PMD_ERR_ARG, "pmd_orthogonalize", "identity right matrix needs m == R");
+    C = G;
+  }
+  float* Et = ar.take_n<float>((size_t)m * m);
+  if (ar.overflow) return pmd_fail(ctx, PMD_ERR_WORKSPACE, "pmd_orthogonalize", "workspace too small");
+  long ldc = M ? m : R;
+  if (M) {
+    RUN(pmd_gemm_rm(ctx, 0, 0, R, m, R, 1.f, G, R, M, ldm, 0.f, GM, m));
+    RUN(pmd_gemm_rm(ctx, 1, 0, m, m, R, 1.f, M, ldm, GM, m, 0.f, C, m));
+  }
+  RUN(pmd_syevd(ctx, m, C, ldc, w, work, info));
+  std::vector<float> hw(m);
+  int hinfo = 0;
+  PMD_HIP(ctx, hipMemcpyAsync(hw.data(), w, (size_t)m * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  PMD_HIP(ctx, hipMemcpyAsync(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  PMD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (hinfo != 0) return pmd_fail(ctx, PMD_ERR_BLAS, "rocsolver_ssyevd", "did not converge");
+  // jnp.linalg.svd(hermitian=True): sort by |lambda| descending, then keep lambda > 0
+  std::vector<int> idx(m);
+  for (int i = 0; i < m; ++i) idx[i] = i;
+  std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return std::fabs(hw[a]) > std::fabs(hw[b]); });
+  std::vector<int> hperm;
+  std::vector<float> hscale;
+  for (int i = 0; i < m; ++i)
+    if (hw[idx[i]] > 0.f) {
+      hperm.push_back(idx[i]);
+      hscale.push_back(1.0f / std::sqrt(hw[idx[i]]));
+    }
+  const int rp = (int)hperm.size();
+  *rprime_out = rp;
+  if (rp == 0) return PMD_OK;
+  PMD_HIP(ctx, hipMemcpyAsync(perm, hperm.data(), (size_t)rp * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  PMD_HIP(ctx, hipMemcpyAsync(scale, hscale.data(), (size_t)rp * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  RUN(launch_gather_rows(ctx, C, ldc, perm, scale, rp, m, Et, m));
+  if (M) RUN(pmd_gemm_rm(ctx, 0, 1, R, rp, m, 1.f, M, ldm, Et, m, 0.f, P_out, ldp));
+  else RUN(launch_transpose(ctx, Et, m, rp, m, P_out, ldp));
+  PMD_HIP(ctx, hipStreamSynchronize(ctx->stream));  // hperm/hscale are host temporaries
+  return PMD_OK;
+}
+
+// ---------------------------------------------------------------- A17 ----------------------
+// projected_svd (decomposition.py:1042-1060) with fewer_rows (:1089-1099) / fewer_columns
+// (:1128-1137).  V: n1 x n2 (row-major, overwritten when n1 <= n2 is false? no: preserved).
+// Outputs: R_out (rows_p x nk), s_out (nk), Vt_out (nk x n2), nk = min(n1, n2).
+size_t pmd_projected_svd_workspace_bytes_impl(int rows_p, int n1, int n2) {
+  const size_t nk = (size_t)std::min(n1, n2);
+  size_t b = nk * nk * sizeof(float) * 2 + nk * (sizeof(float) * 5 + sizeof(int)) + 8192;
+  if (n1 > n2) b += (size_t)n1 * n2 * sizeof(float);
+  return b + 8192;
+}
+
+int pmd_projected_svd_impl(pmd_ctx* ctx, const float* P, int rows_p, long ldp, const float* V, int n1, int n2, long ldv,
+                           float* R_out, long ldr, float* s_out, float* Vt_out, long ldvt, void* ws, size_t ws_bytes) {
+  const int nk = std::min(n1, n2);
+  pmd_arena ar(ws, ws_bytes);
+  float* C = ar.take_n<float>((size_t)nk * nk);
+  float* Wt = ar.take_n<float>((size_t)nk * nk);
+  float* w = ar.take_n<float>(nk);
+  float* work = ar.take_n<float>(nk);
+  float* sgn = ar.take_n<float>(nk);
+  float* inv = ar.take_n<float>(nk);
+  int* perm = ar.take_n<int>(nk);
+  int* info = ar.take_n<int>(4);
+  float* left = (n1 > n2) ? ar.take_n<float>((size_t)n1 * n2) : nullptr;
+  if (ar.overflow) return pmd_fail(ctx, PMD_ERR_WORKSPACE, "pmd_projected_svd", "workspace too small");
+  if (n1 <= n2) RUN(pmd_gemm_rm(ctx, 0, 1, n1, n1, n2, 1.f, V, ldv, V, ldv, 0.f, C, nk));  // V V^T
+  else RUN(pmd_gemm_rm(ctx, 1, 0, n2, n2, n1, 1.f, V, ldv, V, ldv, 0.f, C, nk));           // V^T V
+  RUN(pmd_syevd(ctx, nk, C, nk, w, work, info));
+  std::vector<float> hw(nk);
+  int hinfo = 0;
+  PMD_HIP(ctx, hipMemcpyAsync(hw.data(), w, (size_t)nk * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  PMD_HIP(ctx, hipMemcpyAsync(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  PMD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (hinfo != 0) return pmd_fail(ctx, PMD_ERR_BLAS, "rocsolver_ssyevd", "did not converge");
+  std::vector<int> idx(nk);
+  for (int i = 0; i < nk; ++i) idx[i] = i;
+  std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return std::fabs(hw[a]) > std::fabs(hw[b]); });
+  std::vector<float> hs(nk), hsgn(nk), hinv(nk);
+  for (int i = 0; i < nk; ++i) {
+    const float lam = hw[idx[i]];
+    hs[i] = std::sqrt(std::fabs(lam));
+    hsgn[i] = (lam < 0.f) ? -1.f : 1.f;
+    hinv[i] = (hs[i] == 0.f) ? 1.f : 1.f / hs[i];
+  }
+  PMD_HIP(ctx, hipMemcpyAsync(perm, idx.data(), (size_t)nk * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  PMD_HIP(ctx, hipMemcpyAsync(sgn, hsgn.data(), (size_t)nk * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  PMD_HIP(ctx, hipMemcpyAsync(inv, hinv.data(), (size_t)nk * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  PMD_HIP(ctx, hipMemcpyAsync(s_out, hs.data(), (size_t)nk * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  // Wt[c][:] = sign_c * eigenvector perm[c]
+  RUN(launch_gather_rows(ctx, C, nk, perm, sgn, nk, nk, Wt, nk));
+  if (n1 <= n2) {
+    // Vt = (W^T V) / s ; R = P W
+    RUN(pmd_gemm_rm(ctx, 0, 0, nk, n2, n1, 1.f, Wt, nk, V, ldv, 0.f, Vt_out, ldvt));
+    hipLaunchKernelGGL(scale_rows2_kernel, dim3(8, nk), dim3(256), 0, ctx->stream, Vt_out, ldvt, n2, inv);
+    PMD_LAUNCH_CHECK(ctx, "scale_rows2_kernel");
+    RUN(pmd_gemm_rm(ctx, 0, 1, rows_p, nk, n1, 1.f, P, ldp, Wt, nk, 0.f, R_out, ldr));
+  } else {
+    // right_t = W; left = V (W / s); R = P left; Vt = W^T
+    RUN(pmd_gemm_rm(ctx, 0, 1, n1, nk, n2, 1.f, V, ldv, Wt, nk, 0.f, left, nk));
+    hipLaunchKernelGGL(scale_cols_kernel, dim3(8, n1), dim3(256), 0, ctx->stream, left, (long)nk, nk, inv);
+    PMD_LAUNCH_CHECK(ctx, "scale_cols_kernel");
+    RUN(pmd_gemm_rm(ctx, 0, 0, rows_p, nk, n1, 1.f, P, ldp, left, nk, 0.f, R_out, ldr));
+    PMD_HIP(ctx, hipMemcpy2DAsync(Vt_out, ldvt * sizeof(float), Wt, (size_t)nk * sizeof(float), (size_t)nk * sizeof(float), nk, hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  PMD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return PMD_OK;
+}
+
+// ---------------------------------------------------------------- background projection ----
+// out[k][t] = sum_c basis[c][k] * xs[c][t]  (pmd_loader.py:386, and the K background rows of
+// U^T X in :411).  xs must have round_up(D, 1024) rows allocated (rows >= D zero).
+#define BGP_BLK 1024
+
+__global__ void block_basis_kernel(const float* __restrict__ basis, long D, int K, float* __restrict__ At) {
+  // At[blk][k][q] = basis[blk*BGP_BLK + q][k]
+  const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long blk = c / BGP_BLK;
+  const int q = (int)(c - blk * BGP_BLK);
+  for (int k = 0; k < PMD_RPAD; ++k) At[blk * PMD_RPAD * BGP_BLK + (long)k * BGP_BLK + q] = (c < D && k < K) ? basis[c * K + k] : 0.f;
+}
+
+size_t pmd_bg_project_workspace_bytes_impl(long D, int T) {
+  const size_t nblk = (size_t)((D + BGP_BLK - 1) / BGP_BLK);
+  return nblk * 64 * BGP_BLK * sizeof(float) + nblk * 64 * (size_t)pmd_time_ld(T) * sizeof(float) + 8192;
+}
+
+int pmd_bg_project_impl(pmd_ctx* ctx, const float* xs, long D, int T, long ld, const float* basis, int K, float* out,
+                        long ldo, void* ws, size_t ws_bytes) {
+  if (K < 1 || K > 64) return pmd_fail(ctx, PMD_ERR_UNSUPPORTED, "pmd_bg_project", "background rank must be in [1, 64]");
+  const int nblk = (int)((D + BGP_BLK - 1) / BGP_BLK);
+  const long ldt = pmd_time_ld(T);
+  pmd_arena ar(ws, ws_bytes);
+  float* At = ar.take_n<float>((size_t)nblk * 64 * BGP_BLK);
+  float* part = ar.take_n<float>((size_t)nblk * 64 * ldt);
+  if (ar.overflow) return pmd_fail(ctx, PMD_ERR_WORKSPACE, "pmd_bg_project", "workspace too small");
+  hipLaunchKernelGGL(block_basis_kernel, dim3(nblk * (BGP_BLK / 256)), dim3(256), 0, ctx->stream, basis, D, K, At);
+  PMD_LAUNCH_CHECK(ctx, "block_basis_kernel");
+  RUN(pmd_launch_tile_atx(ctx, xs, ld, nullptr, 0, BGP_BLK, BGP_BLK, At, 64L * BGP_BLK, BGP_BLK, part, 64L * ldt, ldt, nblk, T, 8));
+  // sum the block partials row by row into out[k][0:T]
+  for (int k = 0; k < K; ++k)
+    RUN(pmd_launch_reduce_slices(ctx, part + (long)k * ldt, 0, 64L * ldt, nblk, T, out + (long)k * ldo, 0, 1));
+  return PMD_OK;
+}

@@ -1,0 +1,351 @@
+// Host-side sequencing of the per-tile decomposition, the threshold simulation and the
+// background rSVD.  Everything is enqueued on ctx->stream inside a caller-provided workspace;
+// nothing here allocates or synchronises.
+#include "pmd_internal.h"
+
+int pmd_tile_dpad(int d) {
+  if (d > 2048) return -1;
+  if (d > 1024) return 2048;
+  pmd_dvariant v;
+  if (!pmd_pick_dvariant(d, &v)) return -1;
+  return v.dpad;
+}
+
+long pmd_time_ld(long t) { return pmd_round_up(t, 64) + PMD_LD_SLACK; }
+
+#define RUN(call)                 \
+  do {                            \
+    int rc__ = (call);            \
+    if (rc__ != PMD_OK) return rc__; \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------
+// per-tile decomposition (decomposition.py:235-330 single_block_md, one window, + :501-523)
+// ------------------------------------------------------------------------------------------
+struct tiles_plan {
+  int nb, l, dpad, Ppad, nref;
+  long ld_b;
+  float *abar, *omT, *yt, *qt, *bm, *udst, *ut0, *outA, *spart, *sst;
+  double *gpart, *nmat, *lam;
+  size_t zero_bytes;  // leading part of the workspace that must be zeroed
+};
+
+static const int GRAM_SLICES = 4;
+static const int XBT_SLICES = 4;
+
+static int plan_tiles(pmd_arena& ar, tiles_plan& p, int n, int d, int P, int r, int a, int t_crop, long ldv) {
+  p.nb = t_crop / a;
+  p.l = r + 10;
+  p.dpad = pmd_tile_dpad(d);
+  p.Ppad = pmd_tile_dpad(P);
+  p.nref = (P < p.l) ? P : p.l;
+  p.ld_b = pmd_time_ld(p.nb);
+  if (p.dpad < 0 || p.Ppad < 0) return PMD_ERR_UNSUPPORTED;
+  // arrays with padding that is read before it is written come first (they get zeroed)
+  p.abar = ar.take_n<float>((size_t)n * P * p.ld_b);
+  p.omT = ar.take_n<float>((size_t)n * 64 * p.ld_b);
+  p.yt = ar.take_n<float>((size_t)n * 64 * p.Ppad);
+  p.qt = ar.take_n<float>((size_t)n * 64 * p.Ppad);
+  p.udst = ar.take_n<float>((size_t)n * 64 * p.Ppad);
+  p.ut0 = ar.take_n<float>((size_t)n * 64 * p.dpad);
+  p.spart = ar.take_n<float>((size_t)n * XBT_SLICES * 64 * p.dpad);
+  p.sst = ar.take_n<float>((size_t)n * 64 * p.dpad);
+  p.zero_bytes = ar.used;
+  p.bm = ar.take_n<float>((size_t)n * 64 * p.ld_b);
+  p.outA = ar.take_n<float>((size_t)n * 64 * ldv);
+  p.gpart = ar.take_n<double>((size_t)n * GRAM_SLICES * 4096);
+  p.nmat = ar.take_n<double>((size_t)n * 4096);
+  p.lam = ar.take_n<double>((size_t)n * 64);
+  return PMD_OK;
+}
+
+size_t pmd_tiles_workspace_bytes_impl(int n, int d, int P, int r, int a, int t_crop, long ldv) {
+  pmd_arena ar((void*)0x1000, ~size_t(0) >> 1);
+  tiles_plan p;
+  if (plan_tiles(ar, p, n, d, P, r, a, t_crop, ldv) != PMD_OK) return 0;
+  return ar.used + 4096;
+}
+
+int pmd_tiles_decompose_impl(pmd_ctx* ctx, const float* Xf, long ldx, int t_crop, const int* tile_pix, int n, int b1,
+                             int b2, const int* pool_q, int pool_max, int P, const int* pool_idx, const float* pool_w,
+                             int r, int a, float thr_s, float thr_t, int max_fail, uint64_t seed, uint32_t omega_index0,
+                             uint32_t omega_index_step, float* Ut_out, float* V_out, long ldv, float* stats_out,
+                             int* good_out, int* keep_out, int* ranks_out, double* sing_out, void* ws, size_t ws_bytes) {
+  const int d = b1 * b2;
+  if (r < 1 || r + 10 > 64) return pmd_fail(ctx, PMD_ERR_UNSUPPORTED, "pmd_tiles_decompose", "max_components must be in [1, 54]");
+  if (a < 1 || t_crop % a != 0 || t_crop / a < 1) return pmd_fail(ctx, PMD_ERR_ARG, "pmd_tiles_decompose", "t_crop must be a positive multiple of temporal_avg_factor");
+  if (r > t_crop / a) return pmd_fail(ctx, PMD_ERR_ARG, "pmd_tiles_decompose", "max_components exceeds frames/temporal_avg_factor");
+  if (ldv < pmd_time_ld(t_crop) || ldx < pmd_time_ld(t_crop)) return pmd_fail(ctx, PMD_ERR_ARG, "pmd_tiles_decompose", "leading dimension too small");
+  pmd_arena ar(ws, ws_bytes);
+  tiles_plan p;
+  if (plan_tiles(ar, p, n, d, P, r, a, t_crop, ldv) != PMD_OK)
+    return pmd_fail(ctx, PMD_ERR_UNSUPPORTED, "pmd_tiles_decompose", "tile too large (max 2048 pixels)");
+  if (ar.overflow) return pmd_fail(ctx, PMD_ERR_WORKSPACE, "pmd_tiles_decompose", "workspace too small");
+  if (r > p.nref) return pmd_fail(ctx, PMD_ERR_ARG, "pmd_tiles_decompose", "max_components exceeds pooled pixel count");
+  const long s64d = 64L * p.dpad, s64P = 64L * p.Ppad, s64b = 64L * p.ld_b, s64v = 64L * ldv;
+
+  PMD_HIP(ctx, hipMemsetAsync(ws, 0, p.zero_bytes, ctx->stream));
+  PMD_HIP(ctx, hipMemsetAsync(Ut_out, 0, (size_t)n * s64d * sizeof(float), ctx->stream));
+
+  // --- rSVD of the pooled, temporally binned tile (decomposition.py:279-294, :59-73)
+  RUN(pmd_launch_tile_pool_bin(ctx, Xf, ldx, tile_pix, n, d, pool_q, pool_max, P, a, p.nb, p.abar, p.ld_b, (long)P * p.ld_b));
+  for (int t0 = 0; t0 < n; t0 += 32768) {
+    const int tn = (n - t0 < 32768) ? n - t0 : 32768;
+    RUN(pmd_launch_rng(ctx, seed, PMD_STREAM_TILE_OMEGA, omega_index0 + (uint32_t)t0 * omega_index_step,
+                       omega_index_step, tn, p.nb, p.l, 1, p.omT + (long)t0 * s64b, p.ld_b, s64b));
+  }
+  RUN(pmd_launch_tile_xbt(ctx, p.abar, p.ld_b, nullptr, 0, P, P, p.omT, s64b, p.ld_b, p.yt, s64P, 0, p.Ppad, n, p.nb, 1));
+  RUN(pmd_launch_small_qr(ctx, p.yt, s64P, p.Ppad, P, p.l, p.qt, s64P, p.Ppad, n));
+  RUN(pmd_launch_tile_atx(ctx, p.abar, p.ld_b, nullptr, 0, P, P, p.qt, s64P, p.Ppad, p.bm, s64b, p.ld_b, n, p.nb, 1));
+  RUN(pmd_launch_tile_gram(ctx, p.bm, s64b, p.ld_b, p.nb, n, 1, p.gpart));
+  RUN(pmd_launch_small_eig(ctx, p.gpart, 1, p.nref, 0, 0.0, p.nmat, p.lam, n));
+  RUN(pmd_launch_tile_rowmix(ctx, p.qt, s64P, p.Ppad, p.nmat, 4096, p.nref, r, p.udst, s64P, p.Ppad, P, n));
+  RUN(pmd_launch_expand_pooled(ctx, p.udst, s64P, p.Ppad, pool_idx, pool_w, d, r, p.ut0, s64d, p.dpad, n));
+
+  // --- V_ds = U_ds^T X_ds; basis of its row space (decomposition.py:295-301)
+  RUN(pmd_launch_tile_atx(ctx, Xf, ldx, tile_pix, d, 0, d, p.ut0, s64d, p.dpad, p.outA, s64v, ldv, n, t_crop, 2));
+  RUN(pmd_launch_tile_gram(ctx, p.outA, s64v, ldv, t_crop, n, GRAM_SLICES, p.gpart));
+  RUN(pmd_launch_small_eig(ctx, p.gpart, GRAM_SLICES, r, 1, 1e-10, p.nmat, p.lam, n));
+
+  // --- S = X V_b^T and its left singular vectors U0 (decomposition.py:304-317)
+  RUN(pmd_launch_tile_xbt(ctx, Xf, ldx, tile_pix, d, 0, d, p.outA, s64v, ldv, p.spart, XBT_SLICES * s64d, s64d, p.dpad, n, t_crop, XBT_SLICES));
+  RUN(pmd_launch_reduce_slices(ctx, p.spart, XBT_SLICES * s64d, s64d, XBT_SLICES, s64d, p.sst, s64d, n));
+  RUN(pmd_launch_tile_rowmix(ctx, p.sst, s64d, p.dpad, p.nmat, 4096, r, r, p.sst, s64d, p.dpad, d, n));
+  RUN(pmd_launch_tile_gram(ctx, p.sst, s64d, p.dpad, d, n, 1, p.gpart));
+  RUN(pmd_launch_small_eig(ctx, p.gpart, 1, r, 1, 1e-10, p.nmat, p.lam, n));
+  RUN(pmd_launch_tile_rowmix(ctx, p.sst, s64d, p.dpad, p.nmat, 4096, r, r, p.sst, s64d, p.dpad, d, n));
+
+  // --- W = U0^T X, its SVD rotates U0 and gives sigma*V (decomposition.py:318-323)
+  RUN(pmd_launch_tile_atx(ctx, Xf, ldx, tile_pix, d, 0, d, p.sst, s64d, p.dpad, V_out, s64v, ldv, n, t_crop, 2));
+  RUN(pmd_launch_tile_gram(ctx, V_out, s64v, ldv, t_crop, n, GRAM_SLICES, p.gpart));
+  RUN(pmd_launch_small_eig(ctx, p.gpart, GRAM_SLICES, r, 0, 0.0, p.nmat, sing_out ? sing_out : p.lam, n));
+  RUN(pmd_launch_tile_rowmix(ctx, p.sst, s64d, p.dpad, p.nmat, 4096, r, r, Ut_out, s64d, p.dpad, d, n));
+  RUN(pmd_launch_tile_rowmix(ctx, V_out, s64v, ldv, p.nmat, 4096, r, r, V_out, s64v, ldv, t_crop, n));
+
+  // --- roughness statistics and keep/discard scan (evaluation.py:84-222)
+  RUN(pmd_launch_stats_roughness(ctx, Ut_out, s64d, p.dpad, b1, b2, V_out, s64v, ldv, t_crop, r, stats_out, n));
+  RUN(pmd_launch_decide(ctx, stats_out, r, thr_s, thr_t, max_fail, r, n, good_out, keep_out, ranks_out));
+  return PMD_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// threshold simulation (decomposition.py:76-131, :147-181): rank-1 rSVD of N(0,1) tiles
+// ------------------------------------------------------------------------------------------
+static const int SIM_BATCH = 50;
+
+struct sim_plan {
+  int dpad, nbatch;
+  long ld_t;
+  float *yt, *ypart, *qt, *ut, *noise, *omT, *bm, *stats;
+  double *gpart, *nmat, *lam;
+  size_t zero_bytes;
+};
+
+static int plan_sim(pmd_arena& ar, sim_plan& p, int d, int t, int iters) {
+  p.dpad = pmd_tile_dpad(d);
+  if (p.dpad < 0) return PMD_ERR_UNSUPPORTED;
+  p.nbatch = iters < SIM_BATCH ? iters : SIM_BATCH;
+  p.ld_t = pmd_time_ld(t);
+  const size_t nb = p.nbatch;
+  p.ypart = ar.take_n<float>(nb * XBT_SLICES * 64 * p.dpad);
+  p.yt = ar.take_n<float>(nb * 64 * p.dpad);
+  p.qt = ar.take_n<float>(nb * 64 * p.dpad);
+  p.ut = ar.take_n<float>(nb * 64 * p.dpad);
+  p.omT = ar.take_n<float>(nb * 64 * p.ld_t);
+  p.noise = ar.take_n<float>(nb * d * p.ld_t);
+  p.zero_bytes = ar.used;
+  p.bm = ar.take_n<float>(nb * 64 * p.ld_t);
+  p.stats = ar.take_n<float>(nb * 64 * 2);
+  p.gpart = ar.take_n<double>(nb * GRAM_SLICES * 4096);
+  p.nmat = ar.take_n<double>(nb * 4096);
+  p.lam = ar.take_n<double>(nb * 64);
+  return PMD_OK;
+}
+
+size_t pmd_sim_workspace_bytes_impl(int d, int t, int iters) {
+  pmd_arena ar((void*)0x1000, ~size_t(0) >> 1);
+  sim_plan p;
+  if (plan_sim(ar, p, d, t, iters) != PMD_OK) return 0;
+  return ar.used + 4096;
+}
+
+__global__ void copy_sim_stats_kernel(const float* __restrict__ stats, int nb, float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nb) {
+    out[2 * i + 0] = stats[(long)i * PMD_RPAD * 2 + 0];
+    out[2 * i + 1] = stats[(long)i * PMD_RPAD * 2 + 1];
+  }
+}
+
+int pmd_threshold_sim_impl(pmd_ctx* ctx, int b1, int b2, int t, int iters, uint64_t seed, float* stats_out, void* ws,
+                           size_t ws_bytes) {
+  const int d = b1 * b2;
+  const int l = 11;  // num_comps = 1, ten oversamples (decomposition.py:59, :708)
+  if (t < 3) return pmd_fail(ctx, PMD_ERR_ARG, "pmd_threshold_sim", "need at least 3 frames");
+  pmd_arena ar(ws, ws_bytes);
+  sim_plan p;
+  if (plan_sim(ar, p, d, t, iters) != PMD_OK) return pmd_fail(ctx, PMD_ERR_UNSUPPORTED, "pmd_threshold_sim", "tile too large");
+  if (ar.overflow) return pmd_fail(ctx, PMD_ERR_WORKSPACE, "pmd_threshold_sim", "workspace too small");
+  const long s64d = 64L * p.dpad, s64t = 64L * p.ld_t;
+  const int nref = d < l ? d : l;
+  for (int it0 = 0; it0 < iters; it0 += p.nbatch) {
+    const int nb = (iters - it0 < p.nbatch) ? iters - it0 : p.nbatch;
+    PMD_HIP(ctx, hipMemsetAsync(ws, 0, p.zero_bytes, ctx->stream));
+    RUN(pmd_launch_rng(ctx, seed, PMD_STREAM_SIM_NOISE, (uint32_t)it0, 1, nb, d, t, 0, p.noise, p.ld_t, (long)d * p.ld_t));
+    RUN(pmd_launch_rng(ctx, seed, PMD_STREAM_SIM_OMEGA, (uint32_t)it0, 1, nb, t, l, 1, p.omT, p.ld_t, s64t));
+    RUN(pmd_launch_tile_xbt(ctx, p.noise, p.ld_t, nullptr, 0, d, d, p.omT, s64t, p.ld_t, p.ypart, XBT_SLICES * s64d, s64d, p.dpad, nb, t, XBT_SLICES));
+    RUN(pmd_launch_reduce_slices(ctx, p.ypart, XBT_SLICES * s64d, s64d, XBT_SLICES, s64d, p.yt, s64d, nb));
+    RUN(pmd_launch_small_qr(ctx, p.yt, s64d, p.dpad, d, l, p.qt, s64d, p.dpad, nb));
+    RUN(pmd_launch_tile_atx(ctx, p.noise, p.ld_t, nullptr, 0, d, d, p.qt, s64d, p.dpad, p.bm, s64t, p.ld_t, nb, t, 4));
+    RUN(pmd_launch_tile_gram(ctx, p.bm, s64t, p.ld_t, t, nb, GRAM_SLICES, p.gpart));
+    RUN(pmd_launch_small_eig(ctx, p.gpart, GRAM_SLICES, nref, 0, 0.0, p.nmat, p.lam, nb));
+    RUN(pmd_launch_tile_rowmix(ctx, p.qt, s64d, p.dpad, p.nmat, 4096, nref, 1, p.ut, s64d, p.dpad, d, nb));
+    RUN(pmd_launch_tile_rowmix(ctx, p.bm, s64t, p.ld_t, p.nmat, 4096, nref, 1, p.bm, s64t, p.ld_t, t, nb));
+    RUN(pmd_launch_stats_roughness(ctx, p.ut, s64d, p.dpad, b1, b2, p.bm, s64t, p.ld_t, t, 1, p.stats, nb));
+    hipLaunchKernelGGL(copy_sim_stats_kernel, dim3((nb + 63) / 64), dim3(64), 0, ctx->stream, p.stats, nb, stats_out + 2L * it0);
+    PMD_LAUNCH_CHECK(ctx, "copy_sim_stats_kernel");
+  }
+  return PMD_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// background basis (pmd_loader.py:46-68, :300-314): rSVD of the standardised sample, with the
+// tall-skinny QR done as CholeskyQR2 in fp64 (Q differs from Householder's by column signs
+// only, which cancel in U = Q u).
+// ------------------------------------------------------------------------------------------
+#define BG_BLK 256
+
+__global__ void sum_gram_blocks_kernel(const double* __restrict__ g, int nblk, double* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 4096) return;
+  double s = 0.0;
+  for (int b = 0; b < nblk; ++b) s += g[(long)b * 4096 + i];
+  out[i] = s;
+}
+
+// G = R^T R (upper R); N[c'][c] = (R^{-1})[c'][c].  Pivots <= tol * max diagonal give a zero column.
+__global__ __launch_bounds__(64) void chol_inverse_kernel(const double* __restrict__ G, int n, double tol,
+                                                          double* __restrict__ N) {
+  __shared__ double R[64][65];
+  __shared__ double Ri[64][65];
+  __shared__ int dead[64];
+  const int t = threadIdx.x;
+  for (int i = 0; i < 64; ++i) { R[i][t] = (i < n && t < n) ? 0.5 * (G[i * 64 + t] + G[t * 64 + i]) : 0.0; Ri[i][t] = 0.0; }
+  __syncthreads();
+  double dmax = 0.0;
+  for (int i = 0; i < n; ++i) dmax = fmax(dmax, R[i][i]);
+  // right-looking Cholesky, upper factor stored in R (row k = R[k][k:])
+  for (int k = 0; k < n; ++k) {
+    const double piv = R[k][k];
+    const bool bad = !(piv > tol * dmax);
+    if (t == 0) dead[k] = bad;
+    __syncthreads();
+    const double rkk = bad ? 1.0 : sqrt(piv);
+    double rkt = 0.0;
+    if (t >= k && t < n) rkt = bad ? ((t == k) ? 1.0 : 0.0) : R[k][t] / rkk;
+    __syncthreads();
+    if (t >= k && t < n) R[k][t] = rkt;
+    __syncthreads();
+    if (!bad) {
+      // trailing update: R[i][j] -= R[k][i] * R[k][j], i,j > k ; thread t owns column j = t
+      if (t > k && t < n)
+        for (int i = k + 1; i <= t; ++i) R[i][t] -= R[k][i] * R[k][t];
+    }
+    __syncthreads();
+  }
+  // invert the upper-triangular factor: thread t solves column t of R * X = I
+  if (t < n) {
+    for (int i = t; i >= 0; --i) {
+      double s = (i == t) ? 1.0 : 0.0;
+      for (int j = i + 1; j <= t; ++j) s -= R[i][j] * Ri[j][t];
+      Ri[i][t] = s / R[i][i];
+    }
+  }
+  __syncthreads();
+  for (int i = 0; i < 64; ++i) {
+    double v = (i < n && t < n) ? Ri[i][t] : 0.0;
+    if (t < n && dead[t]) v = 0.0;
+    N[i * 64 + t] = v;
+  }
+}
+
+__global__ void unblock_basis_kernel(const float* __restrict__ ubt, long D, int K, float* __restrict__ basis) {
+  const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= D) return;
+  const long blk = c / BG_BLK;
+  const int q = (int)(c - blk * BG_BLK);
+  for (int k = 0; k < K; ++k) basis[c * K + k] = ubt[blk * 64 * BG_BLK + (long)k * BG_BLK + q];
+}
+
+struct bg_plan {
+  int nblk;
+  long ld;
+  float *omT, *ypart, *yt, *qt, *bpart, *bm;
+  double *gblk, *gsum, *nmat, *lam;
+  size_t zero_bytes;
+};
+
+static void plan_bg(pmd_arena& ar, bg_plan& p, long D, int n) {
+  p.nblk = (int)((D + BG_BLK - 1) / BG_BLK);
+  p.ld = pmd_time_ld(n);
+  const size_t nb = p.nblk;
+  p.omT = ar.take_n<float>(64 * p.ld);
+  p.ypart = ar.take_n<float>(nb * XBT_SLICES * 64 * BG_BLK);
+  p.yt = ar.take_n<float>(nb * 64 * BG_BLK);
+  p.qt = ar.take_n<float>(nb * 64 * BG_BLK);
+  p.zero_bytes = ar.used;
+  p.bpart = ar.take_n<float>(nb * 64 * p.ld);
+  p.bm = ar.take_n<float>(64 * p.ld);
+  p.gblk = ar.take_n<double>(nb * 4096);
+  p.gsum = ar.take_n<double>(4096);
+  p.nmat = ar.take_n<double>(4096);
+  p.lam = ar.take_n<double>(64);
+}
+
+size_t pmd_bg_workspace_bytes_impl(long D, int n) {
+  pmd_arena ar((void*)0x1000, ~size_t(0) >> 1);
+  bg_plan p;
+  plan_bg(ar, p, D, n);
+  return ar.used + 4096;
+}
+
+// xs: standardised sample, pixel-major [c][f], leading dimension ld >= pmd_time_ld(n), with
+// round_up(D, 256) rows allocated (rows >= D zero).  basis_out: [c][k], K columns.
+int pmd_background_rsvd_impl(pmd_ctx* ctx, const float* xs, long D, int n, long ld, int K, uint64_t seed,
+                             float* basis_out, void* ws, size_t ws_bytes) {
+  const int l = K + 10;
+  if (K < 1 || l > 64) return pmd_fail(ctx, PMD_ERR_UNSUPPORTED, "pmd_background_rsvd", "background_rank must be in [1, 54]");
+  if (ld < pmd_time_ld(n)) return pmd_fail(ctx, PMD_ERR_ARG, "pmd_background_rsvd", "leading dimension too small");
+  pmd_arena ar(ws, ws_bytes);
+  bg_plan p;
+  plan_bg(ar, p, D, n);
+  if (ar.overflow) return pmd_fail(ctx, PMD_ERR_WORKSPACE, "pmd_background_rsvd", "workspace too small");
+  const long s64b = 64L * BG_BLK;
+  const int nblk = p.nblk;
+  PMD_HIP(ctx, hipMemsetAsync(ws, 0, p.zero_bytes, ctx->stream));
+  RUN(pmd_launch_rng(ctx, seed, PMD_STREAM_BG_OMEGA, 0, 0, 1, n, l, 1, p.omT, p.ld, 0));
+  // Y = X Omega, block by block (Y^T blocks)
+  RUN(pmd_launch_tile_xbt(ctx, xs, ld, nullptr, 0, BG_BLK, BG_BLK, p.omT, 0, p.ld, p.ypart, XBT_SLICES * s64b, s64b, BG_BLK, nblk, n, XBT_SLICES));
+  RUN(pmd_launch_reduce_slices(ctx, p.ypart, XBT_SLICES * s64b, s64b, XBT_SLICES, s64b, p.yt, s64b, nblk));
+  // CholeskyQR2
+  const float* src = p.yt;
+  for (int pass = 0; pass < 2; ++pass) {
+    RUN(pmd_launch_tile_gram(ctx, src, s64b, BG_BLK, BG_BLK, nblk, 1, p.gblk));
+    hipLaunchKernelGGL(sum_gram_blocks_kernel, dim3(16), dim3(256), 0, ctx->stream, p.gblk, nblk, p.gsum);
+    PMD_LAUNCH_CHECK(ctx, "sum_gram_blocks_kernel");
+    hipLaunchKernelGGL(chol_inverse_kernel, dim3(1), dim3(64), 0, ctx->stream, p.gsum, l, 1e-13, p.nmat);
+    PMD_LAUNCH_CHECK(ctx, "chol_inverse_kernel");
+    RUN(pmd_launch_tile_rowmix(ctx, src, s64b, BG_BLK, p.nmat, 0, l, l, p.qt, s64b, BG_BLK, BG_BLK, nblk));
+    src = p.qt;
+  }
+  // B = Q^T X (sum of block contributions), SVD via Gram
+  RUN(pmd_launch_tile_atx(ctx, xs, ld, nullptr, 0, BG_BLK, BG_BLK, p.qt, s64b, BG_BLK, p.bpart, 64L * p.ld, p.ld, nblk, n, 1));
+  RUN(pmd_launch_reduce_slices(ctx, p.bpart, 0, 64L * p.ld, nblk, 64L * p.ld, p.bm, 0, 1));
+  RUN(pmd_launch_tile_gram(ctx, p.bm, 0, p.ld, n, 1, 1, p.gblk));
+  RUN(pmd_launch_small_eig(ctx, p.gblk, 1, l, 0, 0.0, p.nmat, p.lam, 1));
+  // U = Q u[:, :K]
+  RUN(pmd_launch_tile_rowmix(ctx, p.qt, s64b, BG_BLK, p.nmat, 0, l, K, p.qt, s64b, BG_BLK, BG_BLK, nblk));
+  hipLaunchKernelGGL(unblock_basis_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, ctx->stream, p.qt, D, K, basis_out);
+  PMD_LAUNCH_CHECK(ctx, "unblock_basis_kernel");
+  return PMD_OK;
+}

@@ -1,0 +1,87 @@
+// Internal header of libpmd_hip.so (gfx950 only).  Public C ABI: include/pmd_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <rocblas/rocblas.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#define PMD_OK 0
+#define PMD_ERR_HIP -1
+#define PMD_ERR_ARG -2
+#define PMD_ERR_WORKSPACE -3
+#define PMD_ERR_BLAS -4
+#define PMD_ERR_UNSUPPORTED -5
+
+#define PMD_RPAD 64          // component rows of every per-tile [comp][x] array
+#define PMD_LD_SLACK 64      // extra floats at the end of every time-contiguous row
+
+// random streams (oracle/philox.py holds the same numbers)
+#define PMD_STREAM_BG_OMEGA 1
+#define PMD_STREAM_SIM_NOISE 2
+#define PMD_STREAM_SIM_OMEGA 3
+#define PMD_STREAM_TILE_OMEGA 4
+#define PMD_STREAM_PRUNE 5
+
+struct pmd_ctx {
+  int device;
+  hipStream_t stream;
+  rocblas_handle blas;
+  float* tables;  // device: Hann window + FFT twiddles, see prep.hip
+  char err[512];
+};
+
+static inline int pmd_fail(pmd_ctx* ctx, int code, const char* what, const char* detail) {
+  if (ctx) snprintf(ctx->err, sizeof(ctx->err), "%s: %s", what, detail ? detail : "");
+  return code;
+}
+
+#define PMD_HIP(ctx, call)                                                        \
+  do {                                                                            \
+    hipError_t e__ = (call);                                                      \
+    if (e__ != hipSuccess) return pmd_fail(ctx, PMD_ERR_HIP, #call, hipGetErrorString(e__)); \
+  } while (0)
+
+#define PMD_LAUNCH_CHECK(ctx, name)                                               \
+  do {                                                                            \
+    hipError_t e__ = hipGetLastError();                                           \
+    if (e__ != hipSuccess) return pmd_fail(ctx, PMD_ERR_HIP, name, hipGetErrorString(e__)); \
+  } while (0)
+
+static inline long pmd_round_up(long x, long m) { return (x + m - 1) / m * m; }
+
+// carve a caller-provided workspace
+struct pmd_arena {
+  char* base;
+  size_t size;
+  size_t used;
+  bool overflow;
+  pmd_arena(void* p, size_t n) : base((char*)p), size(n), used(0), overflow(false) {}
+  void* take(size_t bytes) {
+    size_t off = (used + 255) & ~size_t(255);
+    used = off + bytes;
+    if (base == nullptr || used > size) {
+      overflow = true;
+      return nullptr;
+    }
+    return base + off;
+  }
+  template <typename T>
+  T* take_n(size_t n) { return (T*)take(n * sizeof(T)); }
+};
+
+// padded pixel count of a tile and the tile_atx kernel variant that serves it
+struct pmd_dvariant {
+  int kjw;   // 16-row groups per wave
+  int ks;    // K split (waves = 4*ks)
+  int tc;    // frames per chunk
+  int dpad;  // = 16*kjw*ks
+};
+static inline bool pmd_pick_dvariant(int d, pmd_dvariant* v) {
+  static const pmd_dvariant table[] = {
+      {16, 1, 32, 256}, {25, 1, 32, 400}, {32, 1, 32, 512},
+      {25, 2, 32, 800}, {32, 2, 32, 1024}, {25, 4, 16, 1600}};
+  for (const auto& t : table)
+    if (d <= t.dpad) { *v = t; return true; }
+  return false;
+}

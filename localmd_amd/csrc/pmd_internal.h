@@ -1,0 +1,89 @@
+// Launchers shared between the translation units of libpmd_hip.so.
+#pragma once
+#include "pmd_common.h"
+
+int pmd_init_tables(pmd_ctx* ctx);
+extern "C" {
+int pmd_tile_dpad(int d);
+long pmd_time_ld(long t);
+size_t pmd_stats_workspace_bytes(int T, long D, int frame_const);
+}
+
+// rng.hip
+int pmd_launch_rng(pmd_ctx* ctx, uint64_t seed, uint32_t stream, uint32_t index0, uint32_t index_step, int batch,
+                   long rows, int cols, int transpose, float* out, long ld, long batch_stride);
+
+// prep.hip
+int pmd_launch_stats(pmd_ctx* ctx, const float* movie, int T, long D, int frame_const, int do_noise, float* mean_out,
+                     float* std_out, void* ws, size_t ws_bytes);
+int pmd_launch_standardize_transpose(pmd_ctx* ctx, const float* movie, long D, const int* frames, int nf,
+                                     const float* mean, const float* stdv, float* out, long ld);
+int pmd_launch_filter(pmd_ctx* ctx, const float* in, float* out, long D, int nf, long ld, const float* basis, int K,
+                      const float* pj, long ldp);
+int pmd_launch_scale_rows(pmd_ctx* ctx, float* x, long D, int nf, long ld, const float* w);
+int pmd_launch_tile_pool_bin(pmd_ctx* ctx, const float* X, long ldx, const int* pix, int n_tiles, int d,
+                             const int* pool_q, int pool_max, int P, int a, int nbins, float* abar, long ld_ab,
+                             long tile_stride);
+
+// tile_gemm.hip
+int pmd_launch_tile_atx(pmd_ctx* ctx, const float* X, long ldx, const int* pix, int pix_stride, long row0_stride, int d,
+                        const float* A, long a_tile_stride, int a_ld, float* Out, long out_tile_stride, long ldo,
+                        int n_tiles, int T, int slices);
+int pmd_launch_tile_xbt(pmd_ctx* ctx, const float* X, long ldx, const int* pix, int pix_stride, long row0_stride, int d,
+                        const float* B, long b_tile_stride, long ldb, float* S, long s_tile_stride,
+                        long s_slice_stride, int s_ld, int n_tiles, int T, int slices);
+int pmd_launch_tile_gram(pmd_ctx* ctx, const float* In, long tile_stride, long ld, int len, int n_tiles, int slices,
+                         double* G);
+int pmd_launch_reduce_slices(pmd_ctx* ctx, const float* in, long tile_stride, long slice_stride, int slices, long n,
+                             float* out, long out_tile_stride, int n_tiles);
+int pmd_launch_tile_rowmix(pmd_ctx* ctx, const float* In, long in_tile_stride, long ld_in, const double* N,
+                           long n_tile_stride, int n_in, int n_out, float* Out, long out_tile_stride, long ld_out,
+                           int len, int n_tiles);
+
+// small_la.hip
+int pmd_launch_small_qr(pmd_ctx* ctx, const float* Yt, long y_tile_stride, int y_ld, int P, int l, float* Qt,
+                        long q_tile_stride, int q_ld, int n_tiles);
+int pmd_launch_small_eig(pmd_ctx* ctx, const double* G, int slices, int n, int mode, double tol, double* Nout,
+                         double* lam_out, int n_tiles);
+int pmd_launch_expand_pooled(pmd_ctx* ctx, const float* In, long in_tile_stride, int in_ld, const int* pool_idx,
+                             const float* pool_w, int d, int r, float* Out, long out_tile_stride, int out_ld,
+                             int n_tiles);
+int pmd_launch_stats_roughness(pmd_ctx* ctx, const float* Ut, long u_tile_stride, int u_ld, int b1, int b2,
+                               const float* V, long v_tile_stride, long v_ld, int T, int r, float* stats, int n_tiles);
+int pmd_launch_decide(pmd_ctx* ctx, const float* stats, int r, float thr_s, float thr_t, int max_fail, int cap,
+                      int n_tiles, int* good, int* keep, int* ranks);
+
+// pipeline.hip
+size_t pmd_tiles_workspace_bytes_impl(int n, int d, int P, int r, int a, int t_crop, long ldv);
+int pmd_tiles_decompose_impl(pmd_ctx* ctx, const float* Xf, long ldx, int t_crop, const int* tile_pix, int n, int b1,
+                             int b2, const int* pool_q, int pool_max, int P, const int* pool_idx, const float* pool_w,
+                             int r, int a, float thr_s, float thr_t, int max_fail, uint64_t seed, uint32_t omega_index0,
+                             uint32_t omega_index_step, float* Ut_out, float* V_out, long ldv, float* stats_out,
+                             int* good_out, int* keep_out, int* ranks_out, double* sing_out, void* ws, size_t ws_bytes);
+size_t pmd_sim_workspace_bytes_impl(int d, int t, int iters);
+int pmd_threshold_sim_impl(pmd_ctx* ctx, int b1, int b2, int t, int iters, uint64_t seed, float* stats_out, void* ws,
+                           size_t ws_bytes);
+size_t pmd_bg_workspace_bytes_impl(long D, int n);
+int pmd_background_rsvd_impl(pmd_ctx* ctx, const float* xs, long D, int n, long ld, int K, uint64_t seed,
+                             float* basis_out, void* ws, size_t ws_bytes);
+
+// global.hip
+int pmd_gemm_rm(pmd_ctx* ctx, int transA, int transB, int m, int n, int k, float alpha, const float* A, long lda,
+                const float* B, long ldb, float beta, float* C, long ldc);
+int pmd_syevd(pmd_ctx* ctx, int n, float* A, long lda, float* w, float* work, int* info);
+int pmd_launch_weight_tiles(pmd_ctx* ctx, const float* Ut, int dpad, const int* pix, int d, const float* w,
+                            const float* cumw, const int* ranks, float* Uw, int n_tiles);
+int pmd_launch_compact_rows(pmd_ctx* ctx, const float* Out, long tile_stride, long ldo, const int* col_off,
+                            const int* ranks, int T, float* Z, long ldz, int n_tiles);
+int pmd_gram_u_impl(pmd_ctx* ctx, const float* Uw, int dpad, int b1, int b2, const int* pix, const int* pairs,
+                    int n_pairs, const int* origins, const int* col_off, const int* ranks, int n_tiles, int Rt,
+                    const float* basis, long D, int K, float* G, long ldg);
+size_t pmd_orthogonalize_workspace_bytes_impl(int R, int m, int has_m);
+int pmd_orthogonalize_impl(pmd_ctx* ctx, float* G, int R, const float* M, int m, long ldm, float* P_out, long ldp,
+                           int* rprime_out, void* ws, size_t ws_bytes);
+size_t pmd_projected_svd_workspace_bytes_impl(int rows_p, int n1, int n2);
+int pmd_projected_svd_impl(pmd_ctx* ctx, const float* P, int rows_p, long ldp, const float* V, int n1, int n2, long ldv,
+                           float* R_out, long ldr, float* s_out, float* Vt_out, long ldvt, void* ws, size_t ws_bytes);
+size_t pmd_bg_project_workspace_bytes_impl(long D, int T);
+int pmd_bg_project_impl(pmd_ctx* ctx, const float* xs, long D, int T, long ld, const float* basis, int K, float* out,
+                        long ldo, void* ws, size_t ws_bytes);

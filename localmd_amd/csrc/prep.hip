@@ -1,0 +1,303 @@
+// Full-movie passes that feed the tile decomposition:
+//   * per-pixel mean and Welch noise estimate   (pmd_loader.py:203-291, preprocessing_utils.py:10-40)
+//   * (Y-mu)/sigma + transpose to pixel-major    (pmd_loader.py:293-298, :374-378, :396-397)
+//   * background filter X - B (B^T X)            (pmd_loader.py:386-387)
+//   * temporal bin average / spatial pooling     (decomposition.py:279-290)
+// Movie layout on entry: Y[t][c], c = i*d2 + j (frames-first, as the dataset hands it over).
+// Working layout: X[c][t], leading dimension ld (multiple of 64, zero padded): each pixel's
+// trace is contiguous, so a tile is a gather of d rows and every row segment is a whole
+// 128-B line whatever the tile origin is.
+#include "pmd_internal.h"
+
+// ---- tables: [0,256) Hann window (periodic); [256,320) cos, [320,384) sin of 2*pi*k/128;
+//              [384,513) cos, [513,642) sin of 2*pi*k/256 (k = 0..128)
+#define TAB_WIN 0
+#define TAB_C128 256
+#define TAB_S128 320
+#define TAB_C256 384
+#define TAB_S256 513
+#define TAB_SIZE 642
+
+int pmd_init_tables(pmd_ctx* ctx) {
+  float h[TAB_SIZE];
+  const double two_pi = 6.283185307179586476925286766559;
+  for (int i = 0; i < 256; ++i) h[TAB_WIN + i] = (float)(0.5 - 0.5 * cos(two_pi * i / 256.0));
+  for (int k = 0; k < 64; ++k) {
+    h[TAB_C128 + k] = (float)cos(two_pi * k / 128.0);
+    h[TAB_S128 + k] = (float)sin(two_pi * k / 128.0);
+  }
+  for (int k = 0; k <= 128; ++k) {
+    h[TAB_C256 + k] = (float)cos(two_pi * k / 256.0);
+    h[TAB_S256 + k] = (float)sin(two_pi * k / 256.0);
+  }
+  PMD_HIP(ctx, hipMalloc((void**)&ctx->tables, sizeof(h)));
+  PMD_HIP(ctx, hipMemcpy(ctx->tables, h, sizeof(h), hipMemcpyHostToDevice));
+  return PMD_OK;
+}
+
+__device__ __forceinline__ int bitrev7(int x) { return (int)(__brev((unsigned)x) >> 25); }
+
+// One wave = 64 consecutive pixels x one 1024-frame chunk.  Every lane runs its own pixel's
+// Welch estimate; its 128-point complex FFT lives in an LDS column (index*64 + lane), so lanes
+// never share a bank and no barrier is needed.
+__global__ __launch_bounds__(64) void stats_chunk_kernel(const float* __restrict__ Y, int T, long D, int frame_const,
+                                                         int do_noise, const float* __restrict__ tab,
+                                                         double* __restrict__ chunk_sum, float* __restrict__ chunk_noise) {
+  extern __shared__ float lds[];
+  float* re = lds;
+  float* im = lds + 128 * 64;
+  const int lane = threadIdx.x;
+  const long c = (long)blockIdx.x * 64 + lane;
+  const bool valid = c < D;
+  const long cc = valid ? c : D - 1;
+  const int chunk = blockIdx.y;
+  const int t0 = chunk * frame_const;
+  const int t1 = min(T, t0 + frame_const);
+  const int n = t1 - t0;
+
+  double s = 0.0;
+  for (int t = t0; t < t1; ++t) s += (double)Y[(long)t * D + cc];
+  if (valid) chunk_sum[(long)chunk * D + c] = s;
+  if (!do_noise || n < 256) {
+    if (valid && do_noise) chunk_noise[(long)chunk * D + c] = 0.f;
+    return;
+  }
+  const int nseg = (n - 128) / 128;
+  float acc = 0.f;
+  for (int seg = 0; seg < nseg; ++seg) {
+    const float* yp = Y + (long)(t0 + seg * 128) * D + cc;
+    double msum = 0.0;
+    for (int i = 0; i < 256; ++i) msum += (double)yp[(long)i * D];
+    const float m = (float)(msum * (1.0 / 256.0));
+    for (int i = 0; i < 256; i += 2) {
+      const int pos = bitrev7(i >> 1) * 64 + lane;
+      re[pos] = (yp[(long)i * D] - m) * tab[TAB_WIN + i];
+      im[pos] = (yp[(long)(i + 1) * D] - m) * tab[TAB_WIN + i + 1];
+    }
+    // radix-2 decimation-in-time, in place
+#pragma unroll 1
+    for (int half = 1; half < 128; half <<= 1) {
+      const int tw_step = 64 / half;
+#pragma unroll 4
+      for (int j = 0; j < 64; ++j) {
+        const int k = j & (half - 1);
+        const int i0 = ((j - k) << 1) + k;
+        const int i1 = i0 + half;
+        const float wr = tab[TAB_C128 + k * tw_step];
+        const float wi = -tab[TAB_S128 + k * tw_step];
+        const float ar = re[i0 * 64 + lane], ai = im[i0 * 64 + lane];
+        const float br = re[i1 * 64 + lane], bi = im[i1 * 64 + lane];
+        const float tr = br * wr - bi * wi;
+        const float ti = br * wi + bi * wr;
+        re[i0 * 64 + lane] = ar + tr;
+        im[i0 * 64 + lane] = ai + ti;
+        re[i1 * 64 + lane] = ar - tr;
+        im[i1 * 64 + lane] = ai - ti;
+      }
+    }
+    // real-input unpack for bins 65..128: sum of one-sided power (x2 except Nyquist)
+    float p = 0.f;
+    for (int k = 65; k < 128; ++k) {
+      const float zr = re[k * 64 + lane], zi = im[k * 64 + lane];
+      const float cr = re[(128 - k) * 64 + lane], ci = -im[(128 - k) * 64 + lane];
+      const float er = 0.5f * (zr + cr), ei = 0.5f * (zi + ci);
+      // O = (Z - conj(Z'))/(2i) = (-i/2) * (dr + i di) = (di/2, -dr/2)
+      const float dr = zr - cr, di = zi - ci;
+      const float orr = 0.5f * di, oi = -0.5f * dr;
+      const float wr = tab[TAB_C256 + k], wi = -tab[TAB_S256 + k];
+      const float xr = er + (orr * wr - oi * wi);
+      const float xi = ei + (orr * wi + oi * wr);
+      p += 2.0f * (xr * xr + xi * xi);
+    }
+    const float xn = re[lane] - im[lane];
+    p += xn * xn;
+    acc += p;
+  }
+  // density scaling 1/(fs*sum w^2) = 1/96; mean over segments; 0.5 * Pxx averaged over 64 bins
+  const float val = sqrtf(acc * (1.0f / 96.0f) / (float)nseg * 0.5f / 64.0f);
+  if (valid) chunk_noise[(long)chunk * D + c] = val;
+}
+
+__global__ void stats_finalize_kernel(const double* __restrict__ chunk_sum, const float* __restrict__ chunk_noise,
+                                      int nchunks, int ncounted, long D, int T, int do_noise,
+                                      float* __restrict__ mean_out, float* __restrict__ std_out) {
+  const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= D) return;
+  double s = 0.0;
+  for (int k = 0; k < nchunks; ++k) s += chunk_sum[(long)k * D + c];
+  mean_out[c] = (float)(s / (double)T);
+  if (do_noise && ncounted > 0) {
+    float a = 0.f;
+    for (int k = 0; k < nchunks; ++k) a += chunk_noise[(long)k * D + c] / (float)nchunks;
+    a *= (float)nchunks / (float)ncounted;
+    std_out[c] = (a == 0.f) ? 1.0f : a;
+  } else {
+    std_out[c] = 1.0f;
+  }
+}
+
+size_t pmd_stats_workspace_bytes(int T, long D, int frame_const) {
+  const int nchunks = (T + frame_const - 1) / frame_const;
+  return (size_t)nchunks * D * (sizeof(double) + sizeof(float)) + 1024;
+}
+
+int pmd_launch_stats(pmd_ctx* ctx, const float* movie, int T, long D, int frame_const, int do_noise, float* mean_out,
+                     float* std_out, void* ws, size_t ws_bytes) {
+  const int nchunks = (T + frame_const - 1) / frame_const;
+  pmd_arena ar(ws, ws_bytes);
+  double* csum = ar.take_n<double>((size_t)nchunks * D);
+  float* cnoise = ar.take_n<float>((size_t)nchunks * D);
+  if (ar.overflow) return pmd_fail(ctx, PMD_ERR_WORKSPACE, "pmd_stats", "workspace too small");
+  if (T < 256) do_noise = 0;  // pmd_loader.py:213-214
+  int ncounted = 0;
+  for (int k = 0; k < nchunks; ++k) {
+    const int n = (k + 1 == nchunks) ? T - k * frame_const : frame_const;
+    if (n >= 256) ncounted++;
+  }
+  const size_t lds = 2 * 128 * 64 * sizeof(float);
+  PMD_HIP(ctx, hipFuncSetAttribute((const void*)stats_chunk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(stats_chunk_kernel, dim3((unsigned)((D + 63) / 64), nchunks), dim3(64), lds, ctx->stream, movie, T,
+                     D, frame_const, do_noise, ctx->tables, csum, cnoise);
+  PMD_LAUNCH_CHECK(ctx, "stats_chunk_kernel");
+  hipLaunchKernelGGL(stats_finalize_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, ctx->stream, csum, cnoise,
+                     nchunks, ncounted, D, T, do_noise, mean_out, std_out);
+  PMD_LAUNCH_CHECK(ctx, "stats_finalize_kernel");
+  return PMD_OK;
+}
+
+// ---- standardise + transpose: out[c][f] = (Y[frames[f]][c] - mean[c]) / std[c] ------------
+// 64 pixels x 64 frames per workgroup through a padded LDS tile; columns f in [nf, ld) are
+// written as zeros so that consumers may read whole padded rows.
+__global__ __launch_bounds__(256) void standardize_transpose_kernel(const float* __restrict__ Y, long D,
+                                                                    const int* __restrict__ frames, int nf,
+                                                                    const float* __restrict__ mean,
+                                                                    const float* __restrict__ stdv,
+                                                                    float* __restrict__ out, long ld) {
+  __shared__ float tile[64][65];
+  const long c0 = (long)blockIdx.x * 64;
+  const int f0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const long c = c0 + tx;
+  const float mu = (c < D) ? mean[c] : 0.f;
+  const float sg = (c < D) ? stdv[c] : 1.f;
+  for (int r = ty; r < 64; r += 4) {
+    const int f = f0 + r;
+    float v = 0.f;
+    if (f < nf && c < D) {
+      const long t = frames ? (long)frames[f] : (long)f;
+      v = (Y[t * D + c] - mu) / sg;
+    }
+    tile[r][tx] = v;
+  }
+  __syncthreads();
+  for (int r = ty; r < 64; r += 4) {
+    const long cw = c0 + r;
+    const long f = f0 + tx;
+    if (cw < D && f < ld) out[cw * ld + f] = tile[tx][r];
+  }
+}
+
+int pmd_launch_standardize_transpose(pmd_ctx* ctx, const float* movie, long D, const int* frames, int nf,
+                                     const float* mean, const float* stdv, float* out, long ld) {
+  dim3 grid((unsigned)((D + 63) / 64), (unsigned)((ld + 63) / 64));
+  hipLaunchKernelGGL(standardize_transpose_kernel, grid, dim3(256), 0, ctx->stream, movie, D, frames, nf, mean, stdv,
+                     out, ld);
+  PMD_LAUNCH_CHECK(ctx, "standardize_transpose_kernel");
+  return PMD_OK;
+}
+
+// ---- background filter: out[c][f] = in[c][f] - sum_k basis[c][k] * pj[k][f] ----------------
+// basis is [c][k] row-major (ldb = K); pj is [k][f] with leading dimension ldp.
+template <int KMAX>
+__global__ __launch_bounds__(256) void filter_kernel(const float* __restrict__ in, float* __restrict__ out, long D,
+                                                     int nf, long ld, const float* __restrict__ basis, int K,
+                                                     const float* __restrict__ pj, long ldp) {
+  const long c = blockIdx.y;
+  float b[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) b[k] = (k < K) ? basis[c * K + k] : 0.f;
+  for (long f = (long)blockIdx.x * blockDim.x + threadIdx.x; f < nf; f += (long)gridDim.x * blockDim.x) {
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+      if (k < K) acc = fmaf(b[k], pj[(long)k * ldp + f], acc);
+    out[c * ld + f] = in[c * ld + f] - acc;
+  }
+}
+
+int pmd_launch_filter(pmd_ctx* ctx, const float* in, float* out, long D, int nf, long ld, const float* basis, int K,
+                      const float* pj, long ldp) {
+  if (K > 64) return pmd_fail(ctx, PMD_ERR_UNSUPPORTED, "pmd_filter", "background rank > 64");
+  int bx = (nf + 255) / 256;
+  if (bx > 8) bx = 8;
+  // gridDim.y is limited to 65535: walk the pixels in slabs
+  for (long c0 = 0; c0 < D; c0 += 32768) {
+    const long cn = (D - c0 < 32768) ? D - c0 : 32768;
+    dim3 grid(bx, (unsigned)cn);
+    if (K <= 16)
+      hipLaunchKernelGGL(filter_kernel<16>, grid, dim3(256), 0, ctx->stream, in + c0 * ld, out + c0 * ld, D, nf, ld,
+                         basis + c0 * K, K, pj, ldp);
+    else
+      hipLaunchKernelGGL(filter_kernel<64>, grid, dim3(256), 0, ctx->stream, in + c0 * ld, out + c0 * ld, D, nf, ld,
+                         basis + c0 * K, K, pj, ldp);
+    PMD_LAUNCH_CHECK(ctx, "filter_kernel");
+  }
+  return PMD_OK;
+}
+
+// ---- per-pixel scaling of rows (pixel_weighting, decomposition.py:717-718) ------------------
+__global__ void scale_rows_kernel(float* __restrict__ x, long D, int nf, long ld, const float* __restrict__ w) {
+  const long c = blockIdx.y;
+  const float s = w[c];
+  for (long f = (long)blockIdx.x * blockDim.x + threadIdx.x; f < nf; f += (long)gridDim.x * blockDim.x) x[c * ld + f] *= s;
+}
+
+int pmd_launch_scale_rows(pmd_ctx* ctx, float* x, long D, int nf, long ld, const float* w) {
+  for (long c0 = 0; c0 < D; c0 += 32768) {
+    const long cn = (D - c0 < 32768) ? D - c0 : 32768;
+    hipLaunchKernelGGL(scale_rows_kernel, dim3(8, (unsigned)cn), dim3(256), 0, ctx->stream, x + c0 * ld, D, nf, ld,
+                       w + c0);
+    PMD_LAUNCH_CHECK(ctx, "scale_rows_kernel");
+  }
+  return PMD_OK;
+}
+
+// ---- pooled + temporally binned sketch matrix of every tile (decomposition.py:279-290) -----
+// abar[tile][p][cbin] = (1/|window p|) * sum_{q in window p} mean_{tau in bin} X[pix[tile][q]][a*cbin + tau]
+// pool_q: [P][pool_max] local pixel ids of window p (-1 = padding); rows p in [P, Ppad) are zero.
+__global__ __launch_bounds__(256) void tile_pool_bin_kernel(const float* __restrict__ X, long ldx,
+                                                            const int* __restrict__ pix, int d,
+                                                            const int* __restrict__ pool_q, int pool_max, int P,
+                                                            int a, int nbins, float* __restrict__ abar, long ld_ab,
+                                                            long tile_stride) {
+  const int tile = blockIdx.y;
+  const int p = blockIdx.z;
+  const int* pq = pool_q + (long)p * pool_max;
+  const int* px = pix + (long)tile * d;
+  int cnt = 0;
+  for (int w = 0; w < pool_max; ++w) cnt += (pq[w] >= 0);
+  const float inv = 1.0f / (float)(cnt * a);
+  for (int cb = blockIdx.x * blockDim.x + threadIdx.x; cb < nbins; cb += gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int w = 0; w < pool_max; ++w) {
+      const int q = pq[w];
+      if (q < 0) continue;
+      const float* row = X + (long)px[q] * ldx + (long)cb * a;
+      for (int tau = 0; tau < a; ++tau) s += row[tau];
+    }
+    abar[(long)tile * tile_stride + (long)p * ld_ab + cb] = s * inv;
+  }
+}
+
+int pmd_launch_tile_pool_bin(pmd_ctx* ctx, const float* X, long ldx, const int* pix, int n_tiles, int d,
+                             const int* pool_q, int pool_max, int P, int a, int nbins, float* abar, long ld_ab,
+                             long tile_stride) {
+  int bx = (nbins + 255) / 256;
+  for (int t0 = 0; t0 < n_tiles; t0 += 32768) {
+    const int tn = (n_tiles - t0 < 32768) ? n_tiles - t0 : 32768;
+    hipLaunchKernelGGL(tile_pool_bin_kernel, dim3(bx, tn, P), dim3(256), 0, ctx->stream, X, ldx, pix + (long)t0 * d, d,
+                       pool_q, pool_max, P, a, nbins, abar + (long)t0 * tile_stride, ld_ab, tile_stride);
+    PMD_LAUNCH_CHECK(ctx, "tile_pool_bin_kernel");
+  }
+  return PMD_OK;
+}

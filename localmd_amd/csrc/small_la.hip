@@ -1,0 +1,391 @@
+// Batched small dense factorizations, one workgroup per tile, fp64 in LDS.
+//   small_qr   : reduced Householder QR (LAPACK dgeqr2 + dorg2r conventions), replaces
+//                jnp.linalg.qr at decomposition.py:64 / pmd_loader.py:58
+//   small_eig  : cyclic parallel Jacobi eigensolver of a symmetric n x n Gram matrix (n <= 64);
+//                with the streaming Gram/rowmix kernels it replaces the jnp.linalg.svd calls at
+//                decomposition.py:66, :301, :315-317, :319 (SVD of M as eigh(M M^T))
+//   roughness statistics and the keep/discard scan (evaluation.py:84-126, :133-222)
+#include "pmd_common.h"
+
+// ---------------------------------------------------------------- Householder QR ----------
+// Yt: [tile][comp][q] (fp32), P rows (q < P), l columns (comp < l).  Qt out: [tile][comp][q],
+// rows >= min(P,l) and columns >= P are left untouched (callers pre-zero the buffer).
+template <typename ST>
+__global__ __launch_bounds__(256) void small_qr_kernel(const float* __restrict__ Yt, long y_tile_stride, int y_ld,
+                                                       int P, int l, float* __restrict__ Qt, long q_tile_stride,
+                                                       int q_ld) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int nref = min(P, l);
+  const int ldm = P | 1;  // odd leading dimension: columns start on different banks
+  ST* M = reinterpret_cast<ST*>(smem);                                   // M[c*ldm + i] = Y[i][c]
+  double* tau = reinterpret_cast<double*>(smem + (((size_t)l * ldm * sizeof(ST) + 15) & ~size_t(15)));  // [64]
+  double* scratch = tau + 64;                                            // [256 + 4]
+  const int tid = threadIdx.x;
+  const float* y = Yt + (long)blockIdx.x * y_tile_stride;
+  for (int i = tid; i < l * P; i += 256) {
+    const int c = i / P, q = i - c * P;
+    M[c * ldm + q] = (ST)y[(long)c * y_ld + q];
+  }
+  __syncthreads();
+
+  const int col = tid >> 2, sub = tid & 3;  // four threads per column
+  for (int k = 0; k < nref; ++k) {
+    // sigma = sum_{i>k} Y[i][k]^2
+    double part = 0.0;
+    for (int i = k + 1 + tid; i < P; i += 256) { const double v = (double)M[k * ldm + i]; part += v * v; }
+    scratch[tid] = part;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (tid < s) scratch[tid] += scratch[tid + s];
+      __syncthreads();
+    }
+    if (tid == 0) {
+      const double sigma = scratch[0];
+      const double alpha = (double)M[k * ldm + k];
+      double t = 0.0, scale = 0.0, beta = alpha;
+      if (sigma > 0.0) {
+        const double nrm = sqrt(alpha * alpha + sigma);
+        beta = (alpha >= 0.0) ? -nrm : nrm;
+        t = (beta - alpha) / beta;
+        scale = 1.0 / (alpha - beta);
+      }
+      tau[k] = t;
+      scratch[256] = scale;
+      M[k * ldm + k] = (ST)beta;
+    }
+    __syncthreads();
+    const double scale = scratch[256];
+    const double t = tau[k];
+    for (int i = k + 1 + tid; i < P; i += 256) M[k * ldm + i] = (ST)((double)M[k * ldm + i] * scale);
+    __syncthreads();
+    if (t != 0.0) {
+      for (int j = k + 1 + col; j < l; j += 64) {
+        double dot = 0.0;
+        for (int i = k + 1 + sub; i < P; i += 4) dot += (double)M[k * ldm + i] * (double)M[j * ldm + i];
+        dot += __shfl_xor(dot, 1);
+        dot += __shfl_xor(dot, 2);
+        const double w = t * ((double)M[j * ldm + k] + dot);
+        for (int i = k + 1 + sub; i < P; i += 4) M[j * ldm + i] = (ST)((double)M[j * ldm + i] - w * (double)M[k * ldm + i]);
+        if (sub == 0) M[j * ldm + k] = (ST)((double)M[j * ldm + k] - w);
+      }
+    }
+    __syncthreads();
+  }
+  // columns beyond nref hold only R entries: they are not part of Q
+  // form Q in place (dorg2r), k = nref-1 .. 0
+  for (int k = nref - 1; k >= 0; --k) {
+    const double t = tau[k];
+    if (t != 0.0) {
+      for (int j = k + 1 + col; j < nref; j += 64) {
+        double dot = 0.0;
+        for (int i = k + 1 + sub; i < P; i += 4) dot += (double)M[k * ldm + i] * (double)M[j * ldm + i];
+        dot += __shfl_xor(dot, 1);
+        dot += __shfl_xor(dot, 2);
+        const double w = t * ((double)M[j * ldm + k] + dot);
+        for (int i = k + 1 + sub; i < P; i += 4) M[j * ldm + i] = (ST)((double)M[j * ldm + i] - w * (double)M[k * ldm + i]);
+        if (sub == 0) M[j * ldm + k] = (ST)((double)M[j * ldm + k] - w);
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < P; i += 256) {
+      double v;
+      if (i < k) v = 0.0;
+      else if (i == k) v = 1.0 - t;
+      else v = -t * (double)M[k * ldm + i];
+      M[k * ldm + i] = (ST)v;
+    }
+    __syncthreads();
+  }
+  float* qo = Qt + (long)blockIdx.x * q_tile_stride;
+  for (int i = tid; i < nref * P; i += 256) {
+    const int c = i / P, q = i - c * P;
+    qo[(long)c * q_ld + q] = (float)M[c * ldm + q];
+  }
+}
+
+int pmd_launch_small_qr(pmd_ctx* ctx, const float* Yt, long y_tile_stride, int y_ld, int P, int l, float* Qt,
+                        long q_tile_stride, int q_ld, int n_tiles) {
+  if (n_tiles <= 0) return PMD_OK;
+  if (l > 64) return pmd_fail(ctx, PMD_ERR_UNSUPPORTED, "small_qr", "more than 64 columns");
+  const int ldm = P | 1;
+  const size_t tail = (64 + 260) * sizeof(double) + 16;
+  size_t bytes = (size_t)l * ldm * sizeof(double) + tail;
+  const bool use_double = bytes <= 150 * 1024;
+  if (!use_double) bytes = (size_t)l * ldm * sizeof(float) + tail;
+  if (bytes > 160 * 1024) return pmd_fail(ctx, PMD_ERR_UNSUPPORTED, "small_qr", "matrix does not fit LDS");
+  if (use_double) {
+    PMD_HIP(ctx, hipFuncSetAttribute((const void*)small_qr_kernel<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    hipLaunchKernelGGL(small_qr_kernel<double>, dim3(n_tiles), dim3(256), bytes, ctx->stream, Yt, y_tile_stride, y_ld, P,
+                       l, Qt, q_tile_stride, q_ld);
+  } else {
+    PMD_HIP(ctx, hipFuncSetAttribute((const void*)small_qr_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    hipLaunchKernelGGL(small_qr_kernel<float>, dim3(n_tiles), dim3(256), bytes, ctx->stream, Yt, y_tile_stride, y_ld, P,
+                       l, Qt, q_tile_stride, q_ld);
+  }
+  PMD_LAUNCH_CHECK(ctx, "small_qr_kernel");
+  return PMD_OK;
+}
+
+// ---------------------------------------------------------------- Jacobi eigensolver ------
+// G: [tile][slices][64][64] doubles (summed on load; only the leading n x n block is used).
+// Nout[tile][c'][c] = eigenvector c (descending eigenvalue), component c'.
+//   mode 0: plain eigenvectors
+//   mode 1: column c scaled by 1/sqrt(lambda_c); columns with lambda_c <= tol*lambda_max zeroed
+// lam_out[tile][c] = eigenvalue c (descending); entries >= n are zero.
+#define EIG_LD 65
+__global__ __launch_bounds__(256) void small_eig_kernel(const double* __restrict__ G, long g_tile_stride, int slices,
+                                                        int n, int mode, double tol, double* __restrict__ Nout,
+                                                        double* __restrict__ lam_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* A = reinterpret_cast<double*>(smem);  // [64][EIG_LD]
+  double* V = A + 64 * EIG_LD;                  // [64][EIG_LD]
+  double* cs = V + 64 * EIG_LD;                 // [32][2]
+  int* pq = reinterpret_cast<int*>(cs + 64);    // [32][2]
+  int* flag = pq + 64;                          // [2]
+  int* order = flag + 2;                        // [64]
+  const int tid = threadIdx.x;
+  const double* g = G + (long)blockIdx.x * g_tile_stride;
+  for (int i = tid; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    double s = 0.0;
+    if (r < n && c < n)
+      for (int k = 0; k < slices; ++k) s += g[(long)k * 4096 + r * 64 + c] + g[(long)k * 4096 + c * 64 + r];
+    A[r * EIG_LD + c] = 0.5 * s;
+    V[r * EIG_LD + c] = (r == c) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  const int npad = (n + 1) & ~1;
+  const int half = npad / 2;
+  for (int sweep = 0; sweep < 40; ++sweep) {
+    if (tid == 0) flag[0] = 0;
+    __syncthreads();
+    for (int m = 0; m < npad - 1; ++m) {
+      if (tid < half) {
+        // round-robin pairing: fix player npad-1, rotate the rest
+        int p, q;
+        if (tid == 0) { p = npad - 1; q = m; }
+        else { p = (m + tid) % (npad - 1); q = (m - tid + (npad - 1)) % (npad - 1); }
+        if (p > q) { const int t = p; p = q; q = t; }
+        double c = 1.0, s = 0.0;
+        if (q < n) {
+          const double app = A[p * EIG_LD + p], aqq = A[q * EIG_LD + q], apq = A[p * EIG_LD + q];
+          if (fabs(apq) > 1e-17 * sqrt(fabs(app * aqq)) && fabs(apq) > 1e-300) {
+            const double th = (aqq - app) / (2.0 * apq);
+            const double t = ((th >= 0.0) ? 1.0 : -1.0) / (fabs(th) + sqrt(1.0 + th * th));
+            c = 1.0 / sqrt(1.0 + t * t);
+            s = t * c;
+            if (fabs(apq) > 1e-14 * sqrt(fabs(app * aqq))) flag[0] = 1;
+          }
+        }
+        cs[2 * tid] = c; cs[2 * tid + 1] = s;
+        pq[2 * tid] = p; pq[2 * tid + 1] = q;
+      }
+      __syncthreads();
+      for (int i = tid; i < half * n; i += 256) {
+        const int k = i / n, j = i - k * n;
+        const double c = cs[2 * k], s = cs[2 * k + 1];
+        if (s != 0.0) {
+          const int p = pq[2 * k], q = pq[2 * k + 1];
+          const double ap = A[p * EIG_LD + j], aq = A[q * EIG_LD + j];
+          A[p * EIG_LD + j] = c * ap - s * aq;
+          A[q * EIG_LD + j] = s * ap + c * aq;
+        }
+      }
+      __syncthreads();
+      for (int i = tid; i < half * n; i += 256) {
+        const int k = i / n, j = i - k * n;
+        const double c = cs[2 * k], s = cs[2 * k + 1];
+        if (s != 0.0) {
+          const int p = pq[2 * k], q = pq[2 * k + 1];
+          const double ap = A[j * EIG_LD + p], aq = A[j * EIG_LD + q];
+          A[j * EIG_LD + p] = c * ap - s * aq;
+          A[j * EIG_LD + q] = s * ap + c * aq;
+          const double vp = V[j * EIG_LD + p], vq = V[j * EIG_LD + q];
+          V[j * EIG_LD + p] = c * vp - s * vq;
+          V[j * EIG_LD + q] = s * vp + c * vq;
+        }
+      }
+      __syncthreads();
+    }
+    if (flag[0] == 0) break;
+    __syncthreads();
+  }
+  // rank eigenvalues (descending, ties by index)
+  if (tid < 64) {
+    int rank = 0;
+    if (tid < n) {
+      const double li = A[tid * EIG_LD + tid];
+      for (int j = 0; j < n; ++j) {
+        const double lj = A[j * EIG_LD + j];
+        rank += (lj > li) || (lj == li && j < tid);
+      }
+      order[rank] = tid;
+    }
+  }
+  __syncthreads();
+  double lmax = (n > 0) ? A[order[0] * EIG_LD + order[0]] : 0.0;
+  double* no = Nout + (long)blockIdx.x * 4096;
+  for (int i = tid; i < 4096; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    double v = 0.0;
+    if (r < n && c < n) {
+      const int src = order[c];
+      v = V[r * EIG_LD + src];
+      if (mode == 1) {
+        const double lam = A[src * EIG_LD + src];
+        v = (lam > tol * lmax && lam > 0.0) ? v / sqrt(lam) : 0.0;
+      }
+    }
+    no[i] = v;
+  }
+  if (tid < 64) lam_out[(long)blockIdx.x * 64 + tid] = (tid < n) ? A[order[tid] * EIG_LD + order[tid]] : 0.0;
+}
+
+int pmd_launch_small_eig(pmd_ctx* ctx, const double* G, int slices, int n, int mode, double tol, double* Nout,
+                         double* lam_out, int n_tiles) {
+  if (n_tiles <= 0) return PMD_OK;
+  if (n > 64 || n < 1) return pmd_fail(ctx, PMD_ERR_UNSUPPORTED, "small_eig", "n must be in [1, 64]");
+  const size_t bytes = (size_t)2 * 64 * EIG_LD * sizeof(double) + 64 * sizeof(double) + (64 + 2 + 64) * sizeof(int) + 64;
+  PMD_HIP(ctx, hipFuncSetAttribute((const void*)small_eig_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  hipLaunchKernelGGL(small_eig_kernel, dim3(n_tiles), dim3(256), bytes, ctx->stream, G, (long)slices * 4096, slices, n,
+                     mode, tol, Nout, lam_out);
+  PMD_LAUNCH_CHECK(ctx, "small_eig_kernel");
+  return PMD_OK;
+}
+
+// ---------------------------------------------------------------- pooled basis expansion ---
+// Out[tile][c][q] = In[tile][c][pool_idx[q]] * pool_w[q]   (U_ds^T composed with the pooling map)
+__global__ void expand_pooled_kernel(const float* __restrict__ In, long in_tile_stride, int in_ld,
+                                     const int* __restrict__ pool_idx, const float* __restrict__ pool_w, int d, int r,
+                                     float* __restrict__ Out, long out_tile_stride, int out_ld) {
+  const int tile = blockIdx.y;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < r * d; i += gridDim.x * blockDim.x) {
+    const int c = i / d, q = i - c * d;
+    Out[(long)tile * out_tile_stride + (long)c * out_ld + q] =
+        In[(long)tile * in_tile_stride + (long)c * in_ld + pool_idx[q]] * pool_w[q];
+  }
+}
+
+int pmd_launch_expand_pooled(pmd_ctx* ctx, const float* In, long in_tile_stride, int in_ld, const int* pool_idx,
+                             const float* pool_w, int d, int r, float* Out, long out_tile_stride, int out_ld,
+                             int n_tiles) {
+  int bx = (r * d + 255) / 256;
+  if (bx > 32) bx = 32;
+  for (int t0 = 0; t0 < n_tiles; t0 += 32768) {
+    const int tn = (n_tiles - t0 < 32768) ? n_tiles - t0 : 32768;
+    hipLaunchKernelGGL(expand_pooled_kernel, dim3(bx, tn), dim3(256), 0, ctx->stream, In + (long)t0 * in_tile_stride,
+                       in_tile_stride, in_ld, pool_idx, pool_w, d, r, Out + (long)t0 * out_tile_stride,
+                       out_tile_stride, out_ld);
+    PMD_LAUNCH_CHECK(ctx, "expand_pooled_kernel");
+  }
+  return PMD_OK;
+}
+
+// ---------------------------------------------------------------- roughness statistics ----
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// evaluation.py:84-111.  Ut: [tile][comp][q], q = i + b1*j.  One wave per (tile, comp).
+__global__ __launch_bounds__(64) void spatial_stat_kernel(const float* __restrict__ Ut, long tile_stride, int ld, int b1,
+                                                          int b2, float* __restrict__ stats) {
+  const int tile = blockIdx.y, comp = blockIdx.x;
+  const float* u = Ut + (long)tile * tile_stride + (long)comp * ld;
+  const int d = b1 * b2;
+  float sv = 0.f, sh = 0.f, sa = 0.f;
+  for (int q = threadIdx.x; q < d; q += 64) {
+    const float x = u[q];
+    const int i = q % b1;
+    sa += fabsf(x);
+    if (i + 1 < b1) sv += fabsf(u[q + 1] - x);
+    if (q + b1 < d) sh += fabsf(x - u[q + b1]);
+  }
+  sv = wave_sum(sv); sh = wave_sum(sh); sa = wave_sum(sa);
+  if (threadIdx.x == 0) {
+    const float avg_diff = (sv + sh) / (float)((b1 - 1) * b2 + b1 * (b2 - 1));
+    const float avg_elem = sa / (float)d;
+    stats[((long)tile * PMD_RPAD + comp) * 2 + 0] = avg_diff / avg_elem;
+  }
+}
+
+// evaluation.py:114-126.  V: [tile][comp][t].  One workgroup per (tile, comp).
+__global__ __launch_bounds__(256) void temporal_stat_kernel(const float* __restrict__ V, long tile_stride, long ld, int T,
+                                                            float* __restrict__ stats) {
+  __shared__ float red[2][4];
+  const int tile = blockIdx.y, comp = blockIdx.x;
+  const float* v = V + (long)tile * tile_stride + (long)comp * ld;
+  float num = 0.f, den = 0.f;
+  for (int t = threadIdx.x; t < T; t += 256) {
+    const float x = v[t];
+    den += fabsf(x);
+    if (t >= 1 && t + 1 < T) num += fabsf(v[t - 1] + v[t + 1] - 2.0f * x);
+  }
+  num = wave_sum(num); den = wave_sum(den);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = num; red[1][threadIdx.x >> 6] = den; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float n4 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    const float d4 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    stats[((long)tile * PMD_RPAD + comp) * 2 + 1] = (n4 / (float)(T - 2)) / (d4 / (float)T);
+  }
+}
+
+int pmd_launch_stats_roughness(pmd_ctx* ctx, const float* Ut, long u_tile_stride, int u_ld, int b1, int b2,
+                               const float* V, long v_tile_stride, long v_ld, int T, int r, float* stats,
+                               int n_tiles) {
+  for (int t0 = 0; t0 < n_tiles; t0 += 32768) {
+    const int tn = (n_tiles - t0 < 32768) ? n_tiles - t0 : 32768;
+    if (Ut) {
+      hipLaunchKernelGGL(spatial_stat_kernel, dim3(r, tn), dim3(64), 0, ctx->stream, Ut + (long)t0 * u_tile_stride,
+                         u_tile_stride, u_ld, b1, b2, stats + (long)t0 * PMD_RPAD * 2);
+      PMD_LAUNCH_CHECK(ctx, "spatial_stat_kernel");
+    }
+    if (V) {
+      hipLaunchKernelGGL(temporal_stat_kernel, dim3(r, tn), dim3(256), 0, ctx->stream, V + (long)t0 * v_tile_stride,
+                         v_tile_stride, v_ld, T, stats + (long)t0 * PMD_RPAD * 2);
+      PMD_LAUNCH_CHECK(ctx, "temporal_stat_kernel");
+    }
+  }
+  return PMD_OK;
+}
+
+// evaluation.py:133-164 + :195-222.  keep[tile][c] in {0,1}; ranks[tile] = number kept (capped).
+__global__ void decide_kernel(const float* __restrict__ stats, int r, float thr_s, float thr_t, int max_fail, int cap,
+                              int n_tiles, int* __restrict__ good, int* __restrict__ keep, int* __restrict__ ranks) {
+  const int tile = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tile >= n_tiles) return;
+  int fails = 0, count = 0;
+  bool all_fails = false;
+  for (int c = 0; c < PMD_RPAD; ++c) {
+    int g = 0, k = 0;
+    if (c < r) {
+      const float sp = stats[((long)tile * PMD_RPAD + c) * 2 + 0];
+      const float tp = stats[((long)tile * PMD_RPAD + c) * 2 + 1];
+      g = (sp < thr_s) && (tp < thr_t);
+      if (all_fails) k = 0;
+      else if (!g) {
+        fails++;
+        k = 1;
+        if (fails == max_fail) all_fails = true;
+      } else {
+        fails = 0;
+        k = 1;
+      }
+      if (k && count >= cap) k = 0;
+      count += k;
+    }
+    good[(long)tile * PMD_RPAD + c] = g;
+    keep[(long)tile * PMD_RPAD + c] = k;
+  }
+  ranks[tile] = count;
+}
+
+int pmd_launch_decide(pmd_ctx* ctx, const float* stats, int r, float thr_s, float thr_t, int max_fail, int cap,
+                      int n_tiles, int* good, int* keep, int* ranks) {
+  hipLaunchKernelGGL(decide_kernel, dim3((n_tiles + 63) / 64), dim3(64), 0, ctx->stream, stats, r, thr_s, thr_t,
+                     max_fail, cap, n_tiles, good, keep, ranks);
+  PMD_LAUNCH_CHECK(ctx, "decide_kernel");
+  return PMD_OK;
+}

@@ -1,0 +1,438 @@
+// Streaming contractions over gathered tiles of the pixel-major movie X[c][t].
+//
+//   tile_atx :  Out[tile][comp][t] = sum_q A[tile][comp][q] * X[pix[tile][q]][t]      (r x d)(d x T)
+//               V_ds = U_ds^T X_ds (decomposition.py:295-298), U0^T X (:318), U_b^T X (:390-407,
+//               pmd_loader.py:411), Q^T A (decomposition.py:65)
+//   tile_xbt :  S[tile][slice][comp][q] = sum_{t in slice} X[pix[tile][q]][t] * B[tile][comp][t]   (d x T)(T x r)
+//               X V_b^T (decomposition.py:304-306), A Omega (:63)
+//   tile_gram:  G[tile][slice][i][j] = sum_{x in slice} In[tile][i][x] * In[tile][j][x]  (fp64 accumulate)
+//               Gram matrices behind the four small SVDs of single_block_md (:66, :301, :315-319)
+//   tile_rowmix: Out[tile][c][x] = sum_c' N[tile][c'][c] * In[tile][c'][x]               (fp64 accumulate)
+//
+// Every per-tile [comp][x] array has PMD_RPAD = 64 rows (rows >= rank are zero) so that four
+// waves each own one 16-row MFMA tile.  All fp32 products run on v_mfma_f32_16x16x4_f32
+// (exact fp32 fmaf chains, 64 FLOP/clk/SIMD).
+#include "pmd_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------------------------------
+// tile_atx.  One workgroup = one tile x one run of 32-frame chunks.  Wave (mt, ks) keeps its
+// 16 x (16*KJW) slice of A in registers for the whole run (KJW float4 = 4*KJW VGPRs) and reads
+// the X chunk, shared by all waves, from LDS.  K is walked in a permuted order: k-step (J, s),
+// lane slot kk <-> row q = 16*J + 4*kk + s, so one float4 of A feeds four MFMAs and the LDS
+// rows of one 32-lane group sit 4 rows = 16 banks apart (row stride TC+4 floats): conflict-free.
+// ------------------------------------------------------------------------------------------
+template <int KJW, int KS>
+__global__ __launch_bounds__(256 * KS) void tile_atx_kernel(const float* __restrict__ X, long ldx,
+                                                            const int* __restrict__ pix, int pix_stride,
+                                                            long row0_stride, int d,
+                                                            const float* __restrict__ A, long a_tile_stride, int a_ld,
+                                                            float* __restrict__ Out, long out_tile_stride, long ldo,
+                                                            int n_chunks_total, int chunks_per_slice) {
+  constexpr int NTW = 2;
+  constexpr int TC = 16 * NTW;
+  constexpr int LSTR = TC + 4;
+  constexpr int DPAD = 16 * KJW * KS;
+  constexpr int NTHREADS = 256 * KS;
+  constexpr int QUADS = TC / 4;
+  constexpr int NPRE = (DPAD * QUADS + NTHREADS - 1) / NTHREADS;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* xs = lds;
+  float* red = lds + DPAD * LSTR;
+
+  const int tile = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int mt = wid & 3, ks = wid >> 2;
+  const int n16 = lane & 15, kk = lane >> 4;
+  const int kz = blockIdx.z;           // grid-level K split (d > DPAD)
+  const int qbase = kz * DPAD;
+  const int dloc = min(d - qbase, DPAD);
+
+  const int c_begin = blockIdx.y * chunks_per_slice;
+  const int c_end = min(n_chunks_total, c_begin + chunks_per_slice);
+  if (c_begin >= c_end) return;
+
+  // A fragments
+  f32x4 areg[KJW];
+  {
+    const float* ap = A + (long)tile * a_tile_stride + (long)(16 * mt + n16) * a_ld + qbase + ks * (16 * KJW) + 4 * kk;
+#pragma unroll
+    for (int J = 0; J < KJW; ++J) areg[J] = *reinterpret_cast<const f32x4*>(ap + 16 * J);
+  }
+
+  // loader items of this thread
+  long goff[NPRE];
+  int loff[NPRE];
+#pragma unroll
+  for (int k = 0; k < NPRE; ++k) {
+    const int i = tid + k * NTHREADS;
+    const int q = i / QUADS, j = i - q * QUADS;
+    if (q < dloc) {
+      const long row = pix ? (long)pix[(long)tile * pix_stride + qbase + q] : (long)tile * row0_stride + qbase + q;
+      goff[k] = row * ldx + 4 * j;
+      loff[k] = q * LSTR + 4 * j;
+    } else {
+      goff[k] = -1;
+      loff[k] = 0;
+    }
+  }
+  for (int i = tid; i < DPAD * LSTR; i += NTHREADS) xs[i] = 0.f;
+  __syncthreads();
+
+  f32x4 pre[NPRE];
+#pragma unroll
+  for (int k = 0; k < NPRE; ++k)
+    if (goff[k] >= 0) pre[k] = *reinterpret_cast<const f32x4*>(X + goff[k] + (long)c_begin * TC);
+
+  float* outp = Out + (long)tile * out_tile_stride + (long)(16 * mt + 4 * kk) * ldo + n16;
+  const float* xrd = xs + (ks * 16 * KJW + 4 * kk) * LSTR + n16;
+
+  for (int c = c_begin; c < c_end; ++c) {
+#pragma unroll
+    for (int k = 0; k < NPRE; ++k)
+      if (goff[k] >= 0) *reinterpret_cast<f32x4*>(xs + loff[k]) = pre[k];
+    __syncthreads();
+    if (c + 1 < c_end) {
+#pragma unroll
+      for (int k = 0; k < NPRE; ++k)
+        if (goff[k] >= 0) pre[k] = *reinterpret_cast<const f32x4*>(X + goff[k] + (long)(c + 1) * TC);
+    }
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int J = 0; J < KJW; ++J) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const float a = areg[J][s];
+        const float b0 = xrd[(16 * J + s) * LSTR];
+        const float b1 = xrd[(16 * J + s) * LSTR + 16];
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc1, 0, 0, 0);
+      }
+    }
+    if (KS > 1) {
+      // sum the K slices of the waves that share an M tile
+      if (ks > 0) {
+        float* r = red + (((ks - 1) * 4 + mt) * 2) * 256 + lane;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { r[i * 64] = acc0[i]; r[256 + i * 64] = acc1[i]; }
+      }
+      __syncthreads();
+      if (ks == 0) {
+#pragma unroll
+        for (int o = 1; o < KS; ++o) {
+          const float* r = red + (((o - 1) * 4 + mt) * 2) * 256 + lane;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { acc0[i] += r[i * 64]; acc1[i] += r[256 + i * 64]; }
+        }
+      }
+    }
+    if (ks == 0) {
+      float* o = outp + (long)c * TC;
+      if (gridDim.z == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { o[(long)i * ldo] = acc0[i]; o[(long)i * ldo + 16] = acc1[i]; }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { atomicAdd(&o[(long)i * ldo], acc0[i]); atomicAdd(&o[(long)i * ldo + 16], acc1[i]); }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int KJW, int KS>
+static int launch_atx_variant(pmd_ctx* ctx, const float* X, long ldx, const int* pix, int pix_stride, long row0_stride,
+                              int d, const float* A, long a_tile_stride, int a_ld, float* Out, long out_tile_stride,
+                              long ldo, int n_tiles, int T, int slices, int kz) {
+  constexpr int DPAD = 16 * KJW * KS;
+  const size_t lds = (size_t)(DPAD * 36 + (KS > 1 ? (KS - 1) * 4 * 2 * 256 : 0)) * sizeof(float);
+  auto kern = tile_atx_kernel<KJW, KS>;
+  PMD_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int n_chunks = (T + 31) / 32;
+  if (slices < 1) slices = 1;
+  if (slices > n_chunks) slices = n_chunks;
+  const int cps = (n_chunks + slices - 1) / slices;
+  const int ny = (n_chunks + cps - 1) / cps;
+  // tiles ride on gridDim.x (limit 2^31-1)
+  hipLaunchKernelGGL(kern, dim3(n_tiles, ny, kz), dim3(256 * KS), lds, ctx->stream, X, ldx, pix, pix_stride,
+                     row0_stride, d, A, a_tile_stride, a_ld, Out, out_tile_stride, ldo, n_chunks, cps);
+  PMD_LAUNCH_CHECK(ctx, "tile_atx_kernel");
+  return PMD_OK;
+}
+
+// a_ld must be the padded pixel count returned by pmd_tile_dpad(d); Out rows are PMD_RPAD.
+int pmd_launch_tile_atx(pmd_ctx* ctx, const float* X, long ldx, const int* pix, int pix_stride, long row0_stride, int d,
+                        const float* A, long a_tile_stride, int a_ld, float* Out, long out_tile_stride, long ldo,
+                        int n_tiles, int T, int slices) {
+  if (n_tiles <= 0 || T <= 0) return PMD_OK;
+  int kz = 1;
+  int dv = d;
+  if (d > 1024) {
+    if (d > 2048) return pmd_fail(ctx, PMD_ERR_UNSUPPORTED, "tile_atx", "tile larger than 2048 pixels");
+    kz = 2;
+    dv = 1024;
+    PMD_HIP(ctx, hipMemsetAsync(Out, 0, (size_t)n_tiles * out_tile_stride * sizeof(float), ctx->stream));
+  }
+  pmd_dvariant v;
+  if (!pmd_pick_dvariant(dv, &v)) return pmd_fail(ctx, PMD_ERR_UNSUPPORTED, "tile_atx", "no kernel variant");
+  if (a_ld < kz * v.dpad) return pmd_fail(ctx, PMD_ERR_ARG, "tile_atx", "a_ld smaller than padded tile size");
+#define ATX_CASE(KJW_, KS_)                                                                                         \
+  if (v.kjw == KJW_ && v.ks == KS_)                                                                                 \
+    return launch_atx_variant<KJW_, KS_>(ctx, X, ldx, pix, pix_stride, row0_stride, d, A, a_tile_stride, a_ld, Out, \
+                                         out_tile_stride, ldo, n_tiles, T, slices, kz);
+  ATX_CASE(16, 1)
+  ATX_CASE(25, 1)
+  ATX_CASE(32, 1)
+  ATX_CASE(25, 2)
+  ATX_CASE(32, 2)
+#undef ATX_CASE
+  return pmd_fail(ctx, PMD_ERR_UNSUPPORTED, "tile_atx", "variant not built");
+}
+
+// ------------------------------------------------------------------------------------------
+// tile_xbt.  No LDS: wave w of workgroup (tile, slice, mblock) owns MPW 16-pixel M tiles and all
+// four 16-component N tiles; per 16-frame group every lane loads one float4 of X per M tile
+// (16 rows x 64 B per wave instruction) and one float4 of B per N tile, then issues 4*MPW*4
+// MFMAs.  K order inside a group is permuted like tile_atx (slot kk <-> frame 4*kk + s).
+// Loads run one group ahead of the MFMAs (two register sets).
+// ------------------------------------------------------------------------------------------
+template <int MPW>
+__global__ __launch_bounds__(256) void tile_xbt_kernel(const float* __restrict__ X, long ldx,
+                                                       const int* __restrict__ pix, int pix_stride, long row0_stride,
+                                                       int d, const float* __restrict__ B, long b_tile_stride, long ldb,
+                                                       float* __restrict__ S, long s_tile_stride, long s_slice_stride,
+                                                       int s_ld, int n_groups_total, int groups_per_slice) {
+  const int tile = blockIdx.x;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int n16 = lane & 15, kk = lane >> 4;
+  const int m0 = (blockIdx.z * 4 + wid) * MPW;  // first M tile of this wave
+  const int g_begin = blockIdx.y * groups_per_slice;
+  const int g_end = min(n_groups_total, g_begin + groups_per_slice);
+
+  const float* xrow[MPW];
+  bool mvalid[MPW];
+  float rmask[MPW];
+#pragma unroll
+  for (int i = 0; i < MPW; ++i) {
+    const int q = 16 * (m0 + i) + n16;
+    mvalid[i] = 16 * (m0 + i) < d;  // wave-uniform
+    const int qc = min(q, d - 1);
+    const long row = pix ? (long)pix[(long)tile * pix_stride + qc] : (long)tile * row0_stride + qc;
+    xrow[i] = X + row * ldx + 4 * kk;
+    rmask[i] = (q < d) ? 1.f : 0.f;
+  }
+  const float* brow = B + (long)tile * b_tile_stride + (long)n16 * ldb + 4 * kk;
+
+  f32x4 acc[MPW][4];
+#pragma unroll
+  for (int i = 0; i < MPW; ++i)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (g_begin < g_end && mvalid[0]) {
+    f32x4 a0[MPW], b0[4], a1[MPW], b1[4];
+    auto load = [&](f32x4* a, f32x4* b, int g) {
+      const long t = (long)g * 16;
+#pragma unroll
+      for (int i = 0; i < MPW; ++i)
+        if (mvalid[i]) a[i] = *reinterpret_cast<const f32x4*>(xrow[i] + t);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) b[n] = *reinterpret_cast<const f32x4*>(brow + (long)(16 * n) * ldb + t);
+    };
+    auto compute = [&](const f32x4* a, const f32x4* b) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < MPW; ++i)
+          if (mvalid[i]) {
+            const float av = a[i][s] * rmask[i];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[n][s], acc[i][n], 0, 0, 0);
+          }
+    };
+    load(a0, b0, g_begin);
+    int g = g_begin;
+    for (; g + 1 < g_end; g += 2) {
+      load(a1, b1, g + 1);
+      compute(a0, b0);
+      if (g + 2 < g_end) load(a0, b0, g + 2);
+      compute(a1, b1);
+    }
+    if (g < g_end) compute(a0, b0);
+  }
+
+  float* sp = S + (long)tile * s_tile_stride + (long)blockIdx.y * s_slice_stride;
+#pragma unroll
+  for (int i = 0; i < MPW; ++i) {
+    if (!mvalid[i]) continue;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      // C layout: col = lane&15 -> component, row = 4*(lane>>4) + reg -> pixel
+      float* o = sp + (long)(16 * n + n16) * s_ld + 16 * (m0 + i) + 4 * kk;
+      *reinterpret_cast<f32x4*>(o) = acc[i][n];
+    }
+  }
+}
+
+// S rows have s_ld floats (>= 16*ceil(d/16)); slices partition the frame range.
+int pmd_launch_tile_xbt(pmd_ctx* ctx, const float* X, long ldx, const int* pix, int pix_stride, long row0_stride, int d,
+                        const float* B, long b_tile_stride, long ldb, float* S, long s_tile_stride,
+                        long s_slice_stride, int s_ld, int n_tiles, int T, int slices) {
+  if (n_tiles <= 0 || T <= 0) return PMD_OK;
+  const int n_groups = (T + 15) / 16;
+  if (slices < 1) slices = 1;
+  if (slices > n_groups) slices = n_groups;
+  const int gps = (n_groups + slices - 1) / slices;
+  slices = (n_groups + gps - 1) / gps;
+  const int mtiles = (d + 15) / 16;
+  if (s_ld < 16 * mtiles) return pmd_fail(ctx, PMD_ERR_ARG, "tile_xbt", "s_ld too small");
+  constexpr int MPW = 7;
+  const int mblocks = (mtiles + 4 * MPW - 1) / (4 * MPW);
+  hipLaunchKernelGGL(tile_xbt_kernel<MPW>, dim3(n_tiles, slices, mblocks), dim3(256), 0, ctx->stream, X, ldx, pix,
+                     pix_stride, row0_stride, d, B, b_tile_stride, ldb, S, s_tile_stride, s_slice_stride, s_ld,
+                     n_groups, gps);
+  PMD_LAUNCH_CHECK(ctx, "tile_xbt_kernel");
+  return PMD_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// tile_gram (fp64 accumulation of fp32 inputs).  256 threads = 16 x 16, each a 4 x 4 block.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tile_gram_kernel(const float* __restrict__ In, long tile_stride, long ld,
+                                                        int len, int chunk_per_slice, double* __restrict__ G,
+                                                        long g_tile_stride) {
+  __shared__ float buf[64][33];
+  const int tile = blockIdx.x, slice = blockIdx.y;
+  const int ti = threadIdx.x >> 4, tj = threadIdx.x & 15;
+  const float* in = In + (long)tile * tile_stride;
+  const int x_begin = slice * chunk_per_slice;
+  const int x_end = min(len, x_begin + chunk_per_slice);
+  double acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+  for (int x0 = x_begin; x0 < x_end; x0 += 32) {
+    for (int i = threadIdx.x; i < 64 * 32; i += 256) {
+      const int r = i >> 5, cx = i & 31;
+      buf[r][cx] = (x0 + cx < x_end) ? in[(long)r * ld + x0 + cx] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int cx = 0; cx < 32; ++cx) {
+      double av[4], bv[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) { av[a] = (double)buf[4 * ti + a][cx]; bv[a] = (double)buf[4 * tj + a][cx]; }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = fma(av[a], bv[b], acc[a][b]);
+    }
+    __syncthreads();
+  }
+  double* g = G + (long)tile * g_tile_stride + (long)slice * 4096;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) g[(4 * ti + a) * 64 + 4 * tj + b] = acc[a][b];
+}
+
+// G: [tile][slices][64][64] doubles, g_tile_stride = slices*4096.
+int pmd_launch_tile_gram(pmd_ctx* ctx, const float* In, long tile_stride, long ld, int len, int n_tiles, int slices,
+                         double* G) {
+  if (n_tiles <= 0) return PMD_OK;
+  if (slices < 1) slices = 1;
+  int cps = (len + slices - 1) / slices;
+  cps = (int)pmd_round_up(cps, 32);
+  hipLaunchKernelGGL(tile_gram_kernel, dim3(n_tiles, slices), dim3(256), 0, ctx->stream, In, tile_stride, ld, len, cps,
+                     G, (long)slices * 4096);
+  PMD_LAUNCH_CHECK(ctx, "tile_gram_kernel");
+  return PMD_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// sum over slices:  out[tile][i] = sum_s in[tile][s][i]   (fp32 in, fp64 accumulate, fp32 out)
+// ------------------------------------------------------------------------------------------
+__global__ void reduce_slices_kernel(const float* __restrict__ in, long tile_stride, long slice_stride, int slices,
+                                     long n, float* __restrict__ out, long out_tile_stride) {
+  const int tile = blockIdx.y;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    double s = 0.0;
+    for (int k = 0; k < slices; ++k) s += (double)in[(long)tile * tile_stride + (long)k * slice_stride + i];
+    out[(long)tile * out_tile_stride + i] = (float)s;
+  }
+}
+
+int pmd_launch_reduce_slices(pmd_ctx* ctx, const float* in, long tile_stride, long slice_stride, int slices, long n,
+                             float* out, long out_tile_stride, int n_tiles) {
+  int bx = (int)((n + 255) / 256);
+  if (bx > 64) bx = 64;
+  for (int t0 = 0; t0 < n_tiles; t0 += 32768) {
+    const int tn = (n_tiles - t0 < 32768) ? n_tiles - t0 : 32768;
+    hipLaunchKernelGGL(reduce_slices_kernel, dim3(bx, tn), dim3(256), 0, ctx->stream, in + (long)t0 * tile_stride,
+                       tile_stride, slice_stride, slices, n, out + (long)t0 * out_tile_stride, out_tile_stride);
+    PMD_LAUNCH_CHECK(ctx, "reduce_slices_kernel");
+  }
+  return PMD_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// tile_rowmix: Out[tile][c][x] = sum_{c' < n_in} N[tile][c'][c] * In[tile][c'][x], c < n_out;
+// rows c in [n_out, 64) are zeroed.  In-place safe (a thread owns column x).  N is
+// [tile][64][64] doubles (n_tile_stride = 0 shares one matrix between tiles).
+// ------------------------------------------------------------------------------------------
+template <int NOUT>
+__global__ __launch_bounds__(256) void tile_rowmix_kernel(const float* __restrict__ In, long in_tile_stride, long ld_in,
+                                                          const double* __restrict__ N, long n_tile_stride, int n_in,
+                                                          int n_out, float* __restrict__ Out, long out_tile_stride,
+                                                          long ld_out, int len) {
+  __shared__ double nm[64 * NOUT];
+  const int tile = blockIdx.y;
+  const double* nsrc = N + (long)tile * n_tile_stride;
+  for (int i = threadIdx.x; i < 64 * NOUT; i += 256) {
+    const int cp = i / NOUT, c = i - cp * NOUT;
+    nm[i] = (cp < n_in && c < n_out) ? nsrc[cp * 64 + c] : 0.0;
+  }
+  __syncthreads();
+  const float* in = In + (long)tile * in_tile_stride;
+  float* out = Out + (long)tile * out_tile_stride;
+  for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < len; x += gridDim.x * blockDim.x) {
+    double acc[NOUT];
+#pragma unroll
+    for (int c = 0; c < NOUT; ++c) acc[c] = 0.0;
+    for (int cp = 0; cp < n_in; ++cp) {
+      const double v = (double)in[(long)cp * ld_in + x];
+#pragma unroll
+      for (int c = 0; c < NOUT; ++c) acc[c] = fma(nm[cp * NOUT + c], v, acc[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < NOUT; ++c) out[(long)c * ld_out + x] = (c < n_out) ? (float)acc[c] : 0.f;
+    for (int c = NOUT; c < 64; ++c) out[(long)c * ld_out + x] = 0.f;
+  }
+}
+
+int pmd_launch_tile_rowmix(pmd_ctx* ctx, const float* In, long in_tile_stride, long ld_in, const double* N,
+                           long n_tile_stride, int n_in, int n_out, float* Out, long out_tile_stride, long ld_out,
+                           int len, int n_tiles) {
+  if (n_tiles <= 0 || len <= 0) return PMD_OK;
+  int bx = (len + 255) / 256;
+  if (bx > 64) bx = 64;
+  for (int t0 = 0; t0 < n_tiles; t0 += 32768) {
+    const int tn = (n_tiles - t0 < 32768) ? n_tiles - t0 : 32768;
+    const float* in = In + (long)t0 * in_tile_stride;
+    const double* nn = N + (long)t0 * n_tile_stride;
+    float* out = Out + (long)t0 * out_tile_stride;
+    if (n_out <= 4)
+      hipLaunchKernelGGL(tile_rowmix_kernel<4>, dim3(bx, tn), dim3(256), 0, ctx->stream, in, in_tile_stride, ld_in, nn,
+                         n_tile_stride, n_in, n_out, out, out_tile_stride, ld_out, len);
+    else if (n_out <= 32)
+      hipLaunchKernelGGL(tile_rowmix_kernel<32>, dim3(bx, tn), dim3(256), 0, ctx->stream, in, in_tile_stride, ld_in, nn,
+                         n_tile_stride, n_in, n_out, out, out_tile_stride, ld_out, len);
+    else
+      hipLaunchKernelGGL(tile_rowmix_kernel<64>, dim3(bx, tn), dim3(256), 0, ctx->stream, in, in_tile_stride, ld_in, nn,
+                         n_tile_stride, n_in, n_out, out, out_tile_stride, ld_out, len);
+    PMD_LAUNCH_CHECK(ctx, "tile_rowmix_kernel");
+  }
+  return PMD_OK;
+}

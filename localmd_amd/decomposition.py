@@ -1,0 +1,522 @@
+"""
+localmd_decomposition / compute_lowrank_factorized_svd / projected_svd on MI355X.
+
+Host side of the blockwise-PMD hot path: same call signature, defaults, printed phase
+messages and error behaviour as /root/reference/localmd/decomposition.py:643-909, with every
+numeric stage executed by libpmd_hip.so (include/pmd_hip.h) on the HIP device.  PyTorch is
+used for device memory, streams and H2D/D2H copies only.  There is no CPU fallback.
+
+Additions to the reference signature (keyword-only): ``seed`` (counter-based device RNG seed;
+default: one draw from np.random), ``device`` (HIP device index), ``thresholds`` (inject the
+two roughness cut-offs instead of simulating them), ``sim_iters``, ``return_diagnostics``.
+"""
+import datetime
+import math
+import sys
+import time
+from typing import Callable, Optional
+
+import numpy as np
+import scipy.sparse
+from scipy.sparse import coo_matrix
+
+from . import grid
+from ._lib import Context, ptr, PMDLibraryError, c_p, c_i, C
+from .pmdarray import PMDArray
+
+STREAM_PRUNE = 5
+QUIET = False
+
+
+def display(msg):
+    """Timestamped, flushed phase message (decomposition.py:28-34)."""
+    if QUIET:
+        return
+    tag = "[" + datetime.datetime.today().strftime("%y-%m-%d %H:%M:%S") + "]: "
+    sys.stdout.write(tag + msg + "\n")
+    sys.stdout.flush()
+
+
+def _torch():
+    import torch
+
+    return torch
+
+
+def _i32(ctx, arr):
+    torch = _torch()
+    return torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int32)).to(ctx.device)
+
+
+def _f32(ctx, arr):
+    torch = _torch()
+    return torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to(ctx.device)
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class _Movie:
+    """The (T, D) float32 movie resident in HBM, plus the pixel-major standardised copies."""
+
+    def __init__(self, ctx, dataset_obj, frame_batch_size):
+        torch = _torch()
+        self.ctx = ctx
+        shape = tuple(int(x) for x in dataset_obj.shape)
+        self.T, self.d1, self.d2 = shape
+        self.D = self.d1 * self.d2
+        if isinstance(dataset_obj, torch.Tensor):
+            mv = dataset_obj.to(device=ctx.device, dtype=torch.float32)
+            self.dev = mv.reshape(self.T, self.D).contiguous()
+        else:
+            self.dev = torch.empty((self.T, self.D), dtype=torch.float32, device=ctx.device)
+            step = max(1, int(frame_batch_size))
+            for t0 in range(0, self.T, step):
+                keys = list(range(t0, min(self.T, t0 + step)))
+                chunk = np.asarray(dataset_obj[keys], dtype=np.float32).reshape(len(keys), self.D)
+                self.dev[t0 : t0 + len(keys)].copy_(torch.from_numpy(np.ascontiguousarray(chunk)))
+        self.rows_alloc = _round_up(self.D, 1024)
+
+    def standardized(self, frames, mean, std):
+        """Pixel-major (rows_alloc x ld) standardised frames; frames=None means all, in order."""
+        torch = _torch()
+        ctx = self.ctx
+        nf = self.T if frames is None else len(frames)
+        ld = ctx.lib.pmd_time_ld(nf)
+        out = torch.zeros((self.rows_alloc, ld), dtype=torch.float32, device=ctx.device)
+        fr = None if frames is None else _i32(ctx, frames)
+        ctx.call("pmd_standardize_transpose", ptr(self.dev), self.D, ptr(fr), nf, ptr(mean), ptr(std), ptr(out), ld)
+        return out, ld
+
+
+def _sparse_u(ut_host, ranks, pix_f, block_weights, inv_cumw_rows, n_rows):
+    """Sparse assembly of decomposition.py:812-853 (COO triplets, weights, row normalisation),
+    vectorised.  ut_host: (n_tiles, 64, dpad) float32; pix_f: (n_tiles, d) row ids of the output
+    matrix.  Values are float64: (float64(U) * w) * (1/cumw), like the reference."""
+    n_tiles, _, _ = ut_host.shape
+    d = pix_f.shape[1]
+    offsets = np.concatenate([[0], np.cumsum(ranks)]).astype(np.int64)
+    total = int(offsets[-1])
+    w_flat = block_weights.reshape(-1, order="F").astype(np.float64)
+    rows_l, cols_l, vals_l = [], [], []
+    for rk in np.unique(ranks):
+        if rk == 0:
+            continue
+        sel = np.nonzero(ranks == rk)[0]
+        u = ut_host[sel, :rk, :d].astype(np.float64)            # (m, rk, d)
+        vals = u * w_flat[None, None, :]
+        rows = np.broadcast_to(pix_f[sel][:, None, :], vals.shape)
+        vals = vals * inv_cumw_rows[rows]
+        cols = offsets[sel][:, None, None] + np.arange(rk)[None, :, None]
+        cols = np.broadcast_to(cols, vals.shape)
+        rows_l.append(rows.reshape(-1))
+        cols_l.append(cols.reshape(-1))
+        vals_l.append(vals.reshape(-1))
+    if vals_l:
+        rows = np.concatenate(rows_l)
+        cols = np.concatenate(cols_l)
+        vals = np.concatenate(vals_l)
+        keep = vals != 0  # the reference's dia.dot(coo) drops exact zeros
+        u_r = coo_matrix((vals[keep], (rows[keep], cols[keep])), shape=(n_rows, total))
+    else:
+        u_r = coo_matrix((n_rows, total), dtype=np.float64)
+    return u_r, offsets
+
+
+def _orthogonalize(ctx, G, R, M, m, ldm):
+    """Device A15.  Returns (P tensor (R, ldp), R')."""
+    torch = _torch()
+    mm = m if M is not None else R
+    ldp = mm
+    P = torch.empty((R, ldp), dtype=torch.float32, device=ctx.device)
+    ws_bytes = ctx.lib.pmd_orthogonalize_workspace_bytes(R, mm, 1 if M is not None else 0)
+    ws = ctx.workspace(ws_bytes)
+    rp = c_i(0)
+    ctx.call("pmd_orthogonalize", ptr(G), R, ptr(M), mm, ldm, ptr(P), ldp, C.byref(rp), ptr(ws), ws.numel())
+    return P, int(rp.value)
+
+
+def _projected_svd_dev(ctx, P, rows_p, ldp, V, n1, n2, ldv):
+    torch = _torch()
+    nk = min(n1, n2)
+    R_out = torch.empty((rows_p, nk), dtype=torch.float32, device=ctx.device)
+    s_out = torch.empty((nk,), dtype=torch.float32, device=ctx.device)
+    Vt_out = torch.empty((nk, n2), dtype=torch.float32, device=ctx.device)
+    ws_bytes = ctx.lib.pmd_projected_svd_workspace_bytes(rows_p, n1, n2)
+    ws = ctx.workspace(ws_bytes)
+    ctx.call("pmd_projected_svd", ptr(P), rows_p, ldp, ptr(V), n1, n2, ldv, ptr(R_out), nk, ptr(s_out), ptr(Vt_out), n2,
+             ptr(ws), ws.numel())
+    return R_out, s_out, Vt_out
+
+
+def projected_svd(projection, data, device=None):
+    """(projection @ left, s, right) for the SVD of ``data`` via its Gram matrix
+    (decomposition.py:1013-1060).  Host arrays in, host arrays out; computed on the device."""
+    torch = _torch()
+    ctx = Context(0 if device is None else device)
+    try:
+        d1, d2 = data.shape
+        if d1 <= d2:
+            display("Short matrix, using leftward SVD routine")
+        else:
+            display("Tall matrix, using rightward SVD routine")
+        P = _f32(ctx, np.asarray(projection))
+        V = _f32(ctx, np.asarray(data))
+        R_out, s_out, Vt_out = _projected_svd_dev(ctx, P, P.shape[0], P.shape[1], V, d1, d2, d2)
+        ctx.sync()
+        return R_out.cpu().numpy(), s_out.cpu().numpy(), Vt_out.cpu().numpy()
+    finally:
+        ctx.close()
+
+
+def compute_lowrank_factorized_svd(u: coo_matrix, v: np.ndarray, only_left: bool = False, device=None):
+    """Orthonormalising mixing matrix of the factorisation u @ v (decomposition.py:936-1010).
+    ``u`` is a general scipy sparse matrix here, so U^T U is formed with scipy (as the reference
+    does, :974) and uploaded; the eigendecomposition and all dense products run on the device."""
+    torch = _torch()
+    ctx = Context(0 if device is None else device)
+    try:
+        u = scipy.sparse.csr_matrix(u)
+        R = u.shape[1]
+        G = _f32(ctx, np.asarray((u.T.dot(u)).todense()))
+        v32 = np.ascontiguousarray(v, dtype=np.float32)
+        M = _f32(ctx, v32) if R > v.shape[1] else None
+        P, rp = _orthogonalize(ctx, G, R, M, v.shape[1], v.shape[1])
+        P = P[:, :rp].contiguous()
+        if only_left:
+            ctx.sync()
+            return P.cpu().numpy()
+        utuv = _f32(ctx, np.asarray(u.T.dot(u).dot(v)))
+        nt = torch.empty((rp, v.shape[1]), dtype=torch.float32, device=ctx.device)
+        ctx.call("pmd_gemm", 1, 0, rp, v.shape[1], R, 1.0, ptr(P), rp, ptr(utuv), v.shape[1], 0.0, ptr(nt), v.shape[1])
+        R_out, s_out, Vt_out = _projected_svd_dev(ctx, P, R, rp, nt, rp, v.shape[1], v.shape[1])
+        ctx.sync()
+        return R_out.cpu().numpy(), s_out.cpu().numpy(), Vt_out.cpu().numpy()
+    finally:
+        ctx.close()
+
+
+def localmd_decomposition(
+    dataset_obj,
+    block_sizes: tuple,
+    frame_range: int,
+    max_components: int = 50,
+    background_rank: int = 15,
+    sim_conf: int = 5,
+    frame_batch_size: int = 10000,
+    dtype: str = "float32",
+    num_workers: int = 0,
+    pixel_batch_size: int = 5000,
+    max_consecutive_failures=1,
+    rank_prune: bool = False,
+    rank_prune_factor: float = 0.33,
+    temporal_avg_factor: int = 10,
+    spatial_avg_factor: int = 2,
+    order: str = "F",
+    window_chunks: Optional[int] = None,
+    compute_normalizer: bool = True,
+    pixel_weighting: Optional[np.ndarray] = None,
+    spatial_denoiser: Optional[Callable] = None,
+    temporal_denoiser: Optional[Callable] = None,
+    *,
+    seed: Optional[int] = None,
+    device: Optional[int] = None,
+    thresholds=None,
+    sim_iters: int = 250,
+    return_diagnostics: bool = False,
+    ctx: Optional[Context] = None,
+):
+    torch = _torch()
+    if np.dtype(dtype) != np.float32:
+        raise ValueError("only dtype='float32' is supported (the reference computes in float32 throughout)")
+    if spatial_denoiser is not None or temporal_denoiser is not None:
+        raise NotImplementedError("spatial_denoiser / temporal_denoiser hooks are not available in the HIP pipeline")
+    if order not in ("F", "C"):
+        raise ValueError("order must be 'F' or 'C'")
+    timings = {}
+    t_start = time.perf_counter()
+
+    def lap(name, t0):
+        if return_diagnostics:
+            ctx.sync()
+        timings[name] = timings.get(name, 0.0) + time.perf_counter() - t0
+
+    T, d1, d2 = (int(x) for x in dataset_obj.shape)
+    grid.check_fov_size((d1, d2))
+    own_ctx = ctx is None
+    if own_ctx:
+        ctx = Context(0 if device is None else device)
+    try:
+        lib = ctx.lib
+        if seed is None:
+            seed = int(np.random.randint(0, 2 ** 31 - 1))
+        seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        D = d1 * d2
+
+        # ---- PMDLoader.__init__ (pmd_loader.py:112-173): movie to HBM, statistics, background basis
+        t0 = time.perf_counter()
+        movie = _Movie(ctx, dataset_obj, frame_batch_size)
+        lap("upload", t0)
+        display("Computing Video Statistics")
+        if compute_normalizer:
+            display("We are normalizing each pixel by a noise variance estimate")
+        else:
+            display("We are not normalizing each pixel by a noise variance estimate")
+        display("Calculating mean and noise variance")
+        t0 = time.perf_counter()
+        mean_dev = torch.empty(D, dtype=torch.float32, device=ctx.device)
+        std_dev = torch.empty(D, dtype=torch.float32, device=ctx.device)
+        ws = ctx.workspace(lib.pmd_stats_workspace_bytes(T, D, 1024))
+        ctx.call("pmd_stats", ptr(movie.dev), T, D, 1024, 1 if compute_normalizer else 0, ptr(mean_dev), ptr(std_dev),
+                 ptr(ws), ws.numel())
+        display("Finished mean and noise variance")
+        lap("stats", t0)
+
+        t0 = time.perf_counter()
+        K = int(background_rank)
+        basis_dev = None
+        if K > 0:
+            sample = np.random.choice(list(range(T)), replace=False, size=min(1000, T)).tolist()
+            xs_s, ld_s = movie.standardized(sample, mean_dev, std_dev)
+            basis_dev = torch.empty((D, K), dtype=torch.float32, device=ctx.device)
+            ws = ctx.workspace(lib.pmd_background_rsvd_workspace_bytes(D, len(sample)))
+            ctx.call("pmd_background_rsvd", ptr(xs_s), D, len(sample), ld_s, K, seed, ptr(basis_dev), ptr(ws), ws.numel())
+            del xs_s
+        lap("background", t0)
+
+        # ---- frames to fit on (decomposition.py:678-693)
+        if window_chunks is None:
+            window_chunks = frame_range
+        if T < frame_range:
+            display("WARNING: Specified using more frames than there are in the dataset.")
+            frame_range = T
+            frames = list(range(T))
+            if frame_range <= window_chunks:
+                window_chunks = frame_range
+        else:
+            if frame_range <= window_chunks:
+                window_chunks = frame_range
+            frames = grid.identify_window_chunks(frame_range, T, window_chunks, display=display)
+        display("We are initializing on a total of {} frames".format(len(frames)))
+        Tf = len(frames)
+
+        block_sizes = grid.update_block_sizes(block_sizes, (d1, d2), display=display)
+        b1, b2 = block_sizes
+        d = b1 * b2
+        block_weights = grid.block_weight_matrix(block_sizes, dtype=np.float32)
+
+        # ---- roughness thresholds (decomposition.py:700-711)
+        display("Running Simulations, block dimensions are {} x {} x {} ".format(b1, b2, window_chunks))
+        t0 = time.perf_counter()
+        sim_stats = None
+        if thresholds is None:
+            ws = ctx.workspace(lib.pmd_threshold_sim_workspace_bytes(b1, b2, int(window_chunks), int(sim_iters)))
+            stats_dev = torch.empty((sim_iters, 2), dtype=torch.float32, device=ctx.device)
+            ctx.call("pmd_threshold_sim", b1, b2, int(window_chunks), int(sim_iters), seed, ptr(stats_dev), ptr(ws), ws.numel())
+            ctx.sync()
+            sim_stats = stats_dev.cpu().numpy()
+            spatial_threshold = np.percentile(sim_stats[:, 0], sim_conf)
+            temporal_threshold = np.percentile(sim_stats[:, 1], sim_conf)
+        else:
+            spatial_threshold, temporal_threshold = thresholds
+        lap("simulation", t0)
+
+        # ---- standardise, background-filter, transpose (pmd_loader.py:348-389)
+        display("Loading Data")
+        t0 = time.perf_counter()
+        all_frames = frames == list(range(T))
+        xs_full, ld_T = movie.standardized(None, mean_dev, std_dev)
+        if all_frames:
+            xs_init, ld_f = xs_full, ld_T
+        else:
+            xs_init, ld_f = movie.standardized(frames, mean_dev, std_dev)
+        pj_dev = None
+        if K > 0:
+            pj_dev = torch.zeros((K, ld_f), dtype=torch.float32, device=ctx.device)
+            ws = ctx.workspace(lib.pmd_bg_project_workspace_bytes(D, Tf))
+            ctx.call("pmd_bg_project", ptr(xs_init), D, Tf, ld_f, ptr(basis_dev), K, ptr(pj_dev), ld_f, ptr(ws), ws.numel())
+            xf = torch.zeros_like(xs_init)
+            ctx.call("pmd_bg_filter", ptr(xs_init), ptr(xf), D, Tf, ld_f, ptr(basis_dev), K, ptr(pj_dev), ld_f)
+        else:
+            xf = xs_init.clone() if pixel_weighting is not None else xs_init
+        if pixel_weighting is not None:
+            pw = _f32(ctx, np.asarray(pixel_weighting, dtype=np.float32).reshape(-1))
+            ctx.call("pmd_scale_rows", ptr(xf), D, Tf, ld_f, ptr(pw))
+        lap("standardize_filter", t0)
+
+        # ---- tile grid (decomposition.py:721-773)
+        display("Obtaining blocks and running local SVD")
+        dim_1_iters, dim_2_iters = grid.tile_origins((d1, d2), block_sizes)
+        if temporal_avg_factor >= Tf:
+            raise ValueError("Need at least {} frames".format(temporal_avg_factor))
+        if Tf // temporal_avg_factor <= max_components:
+            display(
+                f"WARNING: temporal avg factor is too big, max rank per block adjusted to {Tf // temporal_avg_factor}.\n"
+                "To avoid this, initialize with more frames or reduce temporal avg factor")
+            max_components = int(Tf // temporal_avg_factor)
+        crop = (Tf // temporal_avg_factor) * temporal_avg_factor
+        if min(window_chunks, crop) < crop:
+            raise NotImplementedError(
+                "window_chunks < frame_range (multi-window residual fitting, decomposition.py:333-387) is not "
+                "available in the HIP pipeline yet")
+        pix_c, origins = grid.tile_pixel_lists((d1, d2), block_sizes, dim_1_iters, dim_2_iters)
+        n_tiles = pix_c.shape[0]
+        pool_q, pool_idx, pool_w, pooled_shape = grid.pooling_maps(block_sizes, int(spatial_avg_factor))
+        P_pool = pool_q.shape[0]
+        dpad = lib.pmd_tile_dpad(d)
+        if dpad < 0 or lib.pmd_tile_dpad(P_pool) < 0:
+            raise ValueError("block of {} x {} pixels is larger than the supported maximum (2048 pixels)".format(b1, b2))
+        if max_components + 10 > 64:
+            raise ValueError("max_components must be <= 54 in the HIP pipeline (got {})".format(max_components))
+        pix_dev = _i32(ctx, pix_c)
+        pool_q_dev, pool_idx_dev, pool_w_dev = _i32(ctx, pool_q), _i32(ctx, pool_idx), _f32(ctx, pool_w)
+
+        t0 = time.perf_counter()
+        r = int(max_components)
+        ldv = ld_f
+        ut_dev = torch.empty((n_tiles, 64, dpad), dtype=torch.float32, device=ctx.device)
+        v_dev = torch.empty((n_tiles, 64, ldv), dtype=torch.float32, device=ctx.device)
+        stats_dev = torch.zeros((n_tiles, 64, 2), dtype=torch.float32, device=ctx.device)
+        good_dev = torch.zeros((n_tiles, 64), dtype=torch.int32, device=ctx.device)
+        keep_dev = torch.zeros((n_tiles, 64), dtype=torch.int32, device=ctx.device)
+        ranks_dev = torch.zeros((n_tiles,), dtype=torch.int32, device=ctx.device)
+        lam_dev = torch.zeros((n_tiles, 64), dtype=torch.float64, device=ctx.device)
+        ws = ctx.workspace(lib.pmd_tiles_workspace_bytes(n_tiles, b1, b2, P_pool, r, int(temporal_avg_factor), crop, ldv))
+        ctx.call("pmd_tiles_decompose", ptr(xf), ld_f, crop, ptr(pix_dev), n_tiles, b1, b2, ptr(pool_q_dev),
+                 pool_q.shape[1], P_pool, ptr(pool_idx_dev), ptr(pool_w_dev), r, int(temporal_avg_factor),
+                 float(np.float32(spatial_threshold)), float(np.float32(temporal_threshold)),
+                 int(max_consecutive_failures), seed, 0, 1, ptr(ut_dev), ptr(v_dev), ldv, ptr(stats_dev), ptr(good_dev),
+                 ptr(keep_dev), ptr(ranks_dev), ptr(lam_dev), ptr(ws), ws.numel())
+        ctx.sync()
+        lap("tiles", t0)
+
+        # ---- sparse assembly (decomposition.py:752-857) on the host: integers + float64 scaling
+        t0 = time.perf_counter()
+        ranks = ranks_dev.cpu().numpy().astype(np.int64)
+        ut_host = ut_dev.cpu().numpy()
+        fov_ids = np.arange(D).reshape((d1, d2), order=order)
+        pix_f = fov_ids.reshape(-1)[pix_c]  # output row id of every tile pixel
+        cumw = grid.cumulative_weights((d1, d2), block_sizes, origins, block_weights)
+        inv_rows = np.zeros(D)
+        inv_rows[fov_ids.reshape(-1)] = 1.0 / cumw.reshape(-1)
+        u_local, offsets = _sparse_u(ut_host, ranks, pix_f, block_weights, inv_rows, D)
+        Rt = int(offsets[-1])
+        if K > 0:
+            basis_host = basis_dev.cpu().numpy()  # rows in C-order pixels
+            basis_rows = np.empty_like(basis_host)
+            basis_rows[fov_ids.reshape(-1)] = basis_host
+            u_r = scipy.sparse.hstack([u_local, coo_matrix(basis_rows)])
+            K_cols = K
+        else:
+            u_r = scipy.sparse.hstack([u_local, coo_matrix((D, 1), dtype=np.float32)])
+            K_cols = 1
+        R = Rt + K_cols
+        display("Normalizing by weights")
+        display("The total rank before pruning is {}".format(u_r.shape[1]))
+        lap("assembly", t0)
+
+        # ---- orthogonalisation (decomposition.py:860-881)
+        display("Performing rank pruning and orthogonalization for fast sparse regression.")
+        t0 = time.perf_counter()
+        Rc = Rt + max(K, 0)  # columns with content (the K<=0 placeholder column is empty)
+        col_off_dev = _i32(ctx, offsets[:-1])
+        w_dev = _f32(ctx, block_weights.reshape(-1, order="F"))
+        cumw_dev = _f32(ctx, cumw.reshape(-1))
+        uw_dev = torch.empty_like(ut_dev)
+        ctx.call("pmd_weight_tiles", ptr(ut_dev), dpad, ptr(pix_dev), d, ptr(w_dev), ptr(cumw_dev), ptr(ranks_dev),
+                 ptr(uw_dev), n_tiles)
+        pairs = grid.overlap_pairs(origins, block_sizes)
+        pairs_dev, origins_dev = _i32(ctx, pairs), _i32(ctx, origins)
+        G = torch.empty((Rc, Rc), dtype=torch.float32, device=ctx.device)
+        ctx.call("pmd_gram_u", ptr(uw_dev), dpad, b1, b2, ptr(pix_dev), ptr(pairs_dev), pairs.shape[0], ptr(origins_dev),
+                 ptr(col_off_dev), ptr(ranks_dev), n_tiles, Rt, ptr(basis_dev), D, max(K, 0), ptr(G), Rc)
+
+        # v_cropped = [tile traces ; background temporal basis] (decomposition.py:844, :932)
+        m_cols = crop
+        vc = torch.zeros((Rc, m_cols), dtype=torch.float32, device=ctx.device)
+        ctx.call("pmd_compact_rows", ptr(v_dev), ldv, ptr(col_off_dev), ptr(ranks_dev), crop, ptr(vc), m_cols, n_tiles)
+        if K > 0:
+            vc[Rt:Rt + K, :] = pj_dev[:, :crop]
+        right = vc
+        if rank_prune:
+            if rank_prune_factor <= 0 or rank_prune_factor > 1:
+                raise ValueError("Rank prune factor should be a value in the interval (0, 1]")
+            min_dimension = min(R, crop)
+            n_rand = int(min_dimension * rank_prune_factor)
+            rand = torch.empty((crop, max(n_rand, 1)), dtype=torch.float32, device=ctx.device)
+            ctx.call("pmd_rng_normal", seed, STREAM_PRUNE, 0, 0, 1, crop, n_rand, 0, ptr(rand), n_rand, 0)
+            right = torch.empty((Rc, n_rand), dtype=torch.float32, device=ctx.device)
+            ctx.call("pmd_gemm", 0, 0, Rc, n_rand, crop, 1.0, ptr(vc), m_cols, ptr(rand), n_rand, 0.0, ptr(right), n_rand)
+            m_cols = n_rand
+        use_right = R > m_cols  # decomposition.py:976 (R counts the placeholder column too)
+        P_dev, rp = _orthogonalize(ctx, G, Rc, right if use_right else None, m_cols, m_cols)
+        ldp = P_dev.shape[1]
+        display("After performing rank reduction, the updated rank is {}".format(rp))
+        del G
+        lap("orthogonalize", t0)
+
+        # ---- V = P^T U^T X over the whole movie (pmd_loader.py:316-346)
+        display("Running sparse regression")
+        t0 = time.perf_counter()
+        if all_frames and ldv == ld_T:
+            proj = v_dev
+        else:
+            del v_dev
+            proj = torch.empty((n_tiles, 64, ld_T), dtype=torch.float32, device=ctx.device)
+        ctx.call("pmd_tiles_project", ptr(xs_full), ld_T, T, ptr(pix_dev), n_tiles, d, ptr(uw_dev), dpad, ptr(proj), ld_T, 2)
+        Z = torch.zeros((Rc, T), dtype=torch.float32, device=ctx.device)
+        ctx.call("pmd_compact_rows", ptr(proj), ld_T, ptr(col_off_dev), ptr(ranks_dev), T, ptr(Z), T, n_tiles)
+        if K > 0:
+            if all_frames:
+                Z[Rt:Rt + K, :] = pj_dev[:, :T]
+            else:
+                pj_full = torch.zeros((K, ld_T), dtype=torch.float32, device=ctx.device)
+                ws = ctx.workspace(lib.pmd_bg_project_workspace_bytes(D, T))
+                ctx.call("pmd_bg_project", ptr(xs_full), D, T, ld_T, ptr(basis_dev), K, ptr(pj_full), ld_T, ptr(ws), ws.numel())
+                Z[Rt:Rt + K, :] = pj_full[:, :T]
+        Vp = torch.empty((rp, T), dtype=torch.float32, device=ctx.device)
+        ctx.call("pmd_gemm", 1, 0, rp, T, Rc, 1.0, ptr(P_dev), ldp, ptr(Z), T, 0.0, ptr(Vp), T)
+        lap("v_projection", t0)
+
+        # ---- final SVD (decomposition.py:894-904)
+        display("Final reformat of data into complete SVD")
+        t0 = time.perf_counter()
+        if rp <= T:
+            display("Short matrix, using leftward SVD routine")
+        else:
+            display("Tall matrix, using rightward SVD routine")
+        R_out, s_out, Vt_out = _projected_svd_dev(ctx, P_dev, Rc, ldp, Vp, rp, T, T)
+        ctx.sync()
+        r_mat = R_out.cpu().numpy()
+        s = s_out.cpu().numpy()
+        vt = Vt_out.cpu().numpy()
+        if K_cols != max(K, 0):
+            r_mat = np.concatenate([r_mat, np.zeros((1, r_mat.shape[1]), dtype=r_mat.dtype)], axis=0)
+        good_components = s != 0
+        r_mat = r_mat[:, good_components]
+        s = s[good_components]
+        vt = vt[good_components, :]
+        lap("final_svd", t0)
+        display("Matrix decomposition completed")
+
+        mean_img = mean_dev.cpu().numpy().reshape(d1, d2)
+        std_img = std_dev.cpu().numpy().reshape(d1, d2)
+        final_movie = PMDArray(u_r, r_mat, s, vt, (T, d1, d2), order, mean_img, std_img)
+        timings["total"] = time.perf_counter() - t_start
+        if not return_diagnostics:
+            return final_movie
+        diag = {
+            "seed": seed, "frames": list(frames), "thresholds": (float(spatial_threshold), float(temporal_threshold)),
+            "sim_stats": sim_stats, "tile_ranks": ranks.astype(np.int32), "tile_stats": stats_dev.cpu().numpy(),
+            "tile_good": good_dev.cpu().numpy(), "tile_keep": keep_dev.cpu().numpy(), "tile_lambda": lam_dev.cpu().numpy(),
+            "tile_ut": ut_host, "origins": origins, "pix": pix_c, "block_weights": block_weights,
+            "max_components": r, "rank_before": R, "rank_after": rp, "timings": timings,
+            "spatial_basis": None if K <= 0 else basis_rows, "crop": crop, "dpad": dpad,
+            "p": P_dev[:, :rp].cpu().numpy(), "v_proj": Vp.cpu().numpy(),
+        }
+        return final_movie, diag
+    finally:
+        if own_ctx:
+            ctx.release_workspace()
+            ctx.close()

@@ -1,0 +1,161 @@
+"""
+Integer bookkeeping of the tile grid (host side, exact): tile origins, pyramid weights,
+pixel lists, pooling windows, overlap pairs, frame sampling, argument validation.
+Mirrors /root/reference/localmd/decomposition.py:528-635 and :695-754.
+"""
+import math
+
+import numpy as np
+
+
+def check_fov_size(fov_dims, min_allowed_value: int = 10) -> None:
+    """ValueError when a FOV dimension is below 10 (decomposition.py:616-635)."""
+    for k in fov_dims:
+        if k < min_allowed_value:
+            raise ValueError(
+                "At least one FOV dimension is lower than {}, too small to process".format(min_allowed_value))
+
+
+def update_block_sizes(blocks, fov_shape, min_block_value: int = 10, display=None) -> list:
+    """Clamp block sizes to the FOV; ValueError below 10 (decomposition.py:572-613)."""
+    if blocks[0] < min_block_value or blocks[1] < min_block_value:
+        raise ValueError(
+            "One of the block dimensions was less than min allowed value of {}, "
+            "set to a larger value".format(min_block_value))
+    out = []
+    for dim in (0, 1):
+        if blocks[dim] > fov_shape[dim]:
+            if display is not None:
+                display("Height blocksize was set to {} but corresponding dimension has size {}. Truncating to {}".format(
+                    blocks[dim], fov_shape[dim], fov_shape[dim]))
+            out.append(int(fov_shape[dim]))
+        else:
+            out.append(int(blocks[dim]))
+    return out
+
+
+def identify_window_chunks(frame_range: int, total_frames: int, window_chunks: int, display=None) -> list:
+    """Contiguous chunks of frames to fit on; draws from the global np.random state exactly like
+    the reference (decomposition.py:528-569)."""
+    if frame_range > total_frames:
+        raise ValueError("Requested more frames than available")
+    if window_chunks > frame_range:
+        raise ValueError("The size of each temporal chunk is bigger than frame range")
+    num_intervals = math.ceil(frame_range / window_chunks)
+    available = np.arange(0, total_frames, window_chunks)
+    if available[-1] > total_frames - window_chunks:
+        available[-1] = total_frames - window_chunks
+    starts = np.sort(np.random.choice(available, size=num_intervals, replace=False))
+    if display is not None:
+        display("sampled from the following regions: {}".format(starts))
+    frames = []
+    for k in starts:
+        frames.extend(range(int(k), int(min(k + window_chunks, total_frames))))
+    return frames
+
+
+def tile_origins(fov, block_sizes):
+    """Origins per dimension: stride b - ceil(b/2), last tile snapped to D - b
+    (decomposition.py:698, :723-739)."""
+    out = []
+    for dim in (0, 1):
+        overlap = math.ceil(block_sizes[dim] / 2)
+        it = list(range(0, fov[dim] - block_sizes[dim] + 1, block_sizes[dim] - overlap))
+        if it[-1] != fov[dim] - block_sizes[dim] and fov[dim] - block_sizes[dim] != 0:
+            it.append(fov[dim] - block_sizes[dim])
+        out.append(it)
+    return out[0], out[1]
+
+
+def block_weight_matrix(block_sizes, dtype=np.float32) -> np.ndarray:
+    """Pyramid weights (decomposition.py:742-750).  Odd block sizes are rejected with a
+    ValueError (the reference fails there with a NumPy broadcast ValueError)."""
+    b1, b2 = int(block_sizes[0]), int(block_sizes[1])
+    if b1 % 2 or b2 % 2:
+        raise ValueError("block sizes must be even (got {} x {})".format(b1, b2))
+    hbh, hbw = b1 // 2, b2 // 2
+    w = np.ones((b1, b2), dtype=dtype)
+    w[:hbh, :hbw] += np.minimum(np.arange(hbw)[None, :], np.arange(hbh)[:, None])
+    w[:hbh, hbw:] = np.fliplr(w[:hbh, :hbw])
+    w[hbh:, :] = np.flipud(w[:hbh, :])
+    return w
+
+
+def tile_pixel_lists(fov, block_sizes, dim_1_iters, dim_2_iters):
+    """pix[tile][q]: C-order FOV pixel (i*d2 + j) of tile-local pixel q = il + b1*jl.
+    Tile order is k-outer / j-inner (decomposition.py:790-792).  Also returns origins[tile]."""
+    d1, d2 = fov
+    b1, b2 = block_sizes
+    il = np.arange(b1)[:, None]
+    jl = np.arange(b2)[None, :]
+    pix, origins = [], []
+    for k in dim_1_iters:
+        for j in dim_2_iters:
+            c = (k + il) * d2 + (j + jl)  # (b1, b2)
+            pix.append(c.reshape(-1, order="F"))
+            origins.append((k, j))
+    return np.asarray(pix, dtype=np.int32), np.asarray(origins, dtype=np.int32)
+
+
+def pooling_maps(block_sizes, n):
+    """n x n mean pooling with XLA SAME padding (decomposition.py:192-232).
+    Returns pool_q (P, n*n) local pixel ids (F order, -1 = out of bounds), pool_idx (d,) window
+    of each pixel (windows in F order), pool_w (d,) = 1/|window|, and the pooled shape."""
+    b1, b2 = block_sizes
+
+    def windows(size):
+        out = -(-size // n)
+        total = max((out - 1) * n + n - size, 0)
+        lo = total // 2
+        return out, lo
+
+    o1, lo1 = windows(b1)
+    o2, lo2 = windows(b2)
+    P = o1 * o2
+    pool_q = -np.ones((P, n * n), dtype=np.int32)
+    pool_idx = np.zeros(b1 * b2, dtype=np.int32)
+    pool_w = np.zeros(b1 * b2, dtype=np.float32)
+    for pj in range(o2):
+        for pi in range(o1):
+            p = pi + o1 * pj
+            members = []
+            for a in range(n):
+                for b in range(n):
+                    i = pi * n + a - lo1
+                    j = pj * n + b - lo2
+                    if 0 <= i < b1 and 0 <= j < b2:
+                        members.append(i + b1 * j)
+            pool_q[p, : len(members)] = members
+            for q in members:
+                pool_idx[q] = p
+                pool_w[q] = 1.0 / len(members)
+    return pool_q, pool_idx, pool_w, (o1, o2)
+
+
+def overlap_pairs(origins, block_sizes):
+    """All (a <= b) tile pairs whose rectangles intersect, with the intersection rectangle
+    (i0, i1, j0, j1) in FOV coordinates.  int32 (n_pairs, 6)."""
+    b1, b2 = block_sizes
+    ks = np.unique(origins[:, 0])
+    js = np.unique(origins[:, 1])
+    index = {(int(k), int(j)): t for t, (k, j) in enumerate(origins)}
+    pairs = []
+    for t, (k, j) in enumerate(origins):
+        for k2 in ks[(ks > k - b1) & (ks < k + b1)]:
+            for j2 in js[(js > j - b2) & (js < j + b2)]:
+                t2 = index[(int(k2), int(j2))]
+                if t2 < t:
+                    continue
+                i0, i1 = max(k, k2), min(k, k2) + b1
+                j0, j1 = max(j, j2), min(j, j2) + b2
+                pairs.append((t, t2, i0, i1, j0, j1))
+    return np.asarray(pairs, dtype=np.int32).reshape(-1, 6)
+
+
+def cumulative_weights(fov, block_sizes, origins, block_weights):
+    """Sum of the tile weights covering each pixel (decomposition.py:813-816), float64 (d1, d2)."""
+    cw = np.zeros(fov, dtype=np.float64)
+    b1, b2 = block_sizes
+    for k, j in origins:
+        cw[k : k + b1, j : j + b2] += block_weights
+    return cw

@@ -1,0 +1,313 @@
+"""
+Kernel-level parity tests (GPU): every hand-written kernel is called through the C ABI
+(include/pmd_hip.h, pmdk_* and pmd_* entry points) and compared with NumPy in float64 or
+with the oracle's restatement of the reference function it replaces.
+"""
+import numpy as np
+import pytest
+
+from oracle import pmd_oracle as O, philox
+from tests.util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _t():
+    import torch
+
+    return torch
+
+
+def dev(ctx, a, dtype=None):
+    torch = _t()
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(ctx.device)
+
+
+def P(t):
+    from localmd_amd._lib import ptr
+
+    return ptr(t)
+
+
+def test_rng_matches_numpy_restatement(gpu_ctx):
+    torch = _t()
+    ctx = gpu_ctx
+    seed = 0x1234ABCD5678
+    rows, cols = 37, 11
+    out = torch.zeros((3, 16, 40), dtype=torch.float32, device=ctx.device)
+    # transposed, batched: out[b][col][row]
+    ctx.call("pmd_rng_normal", seed, 4, 7, 2, 3, rows, cols, 1, P(out), 40, 16 * 40)
+    ctx.sync()
+    got = out.cpu().numpy()
+    for b in range(3):
+        ref = philox.normals(seed, 4, 7 + 2 * b, rows * cols).reshape(rows, cols)
+        np.testing.assert_allclose(got[b, :cols, :rows], ref.T, rtol=0, atol=3e-6)
+        assert np.all(got[b, cols:, :] == 0) and np.all(got[b, :, rows:] == 0)
+    z = torch.empty(1 << 20, dtype=torch.float32, device=ctx.device)
+    ctx.call("pmd_rng_normal", 99, 2, 0, 0, 1, 1 << 20, 1, 0, P(z), 1, 0)
+    ctx.sync()
+    zz = z.cpu().numpy()
+    assert abs(zz.mean()) < 5e-3 and abs(zz.std() - 1) < 5e-3
+
+
+def _atx_case(ctx, d, T, n_tiles, rows, slices, use_pix=True, seed=0):
+    torch = _t()
+    lib = ctx.lib
+    rng = np.random.default_rng(seed)
+    ld = lib.pmd_time_ld(T)
+    dpad = lib.pmd_tile_dpad(d)
+    X = np.zeros((rows, ld), dtype=np.float32)
+    X[:, :T] = rng.standard_normal((rows, T)).astype(np.float32)
+    if use_pix:
+        pix = np.stack([rng.choice(rows, size=d, replace=False) for _ in range(n_tiles)]).astype(np.int32)
+    else:
+        assert rows >= n_tiles * d
+        pix = (np.arange(n_tiles)[:, None] * d + np.arange(d)[None, :]).astype(np.int32)
+    A = np.zeros((n_tiles, 64, dpad), dtype=np.float32)
+    r = 50
+    A[:, :r, :d] = rng.standard_normal((n_tiles, r, d)).astype(np.float32)
+    Out = torch.full((n_tiles, 64, ld), np.nan, dtype=torch.float32, device=ctx.device)
+    Xd, Ad = dev(ctx, X), dev(ctx, A)
+    pd = dev(ctx, pix) if use_pix else None
+    ctx.call("pmdk_tile_atx", P(Xd), ld, P(pd), d, d, d, P(Ad), 64 * dpad, dpad, P(Out), 64 * ld, ld, n_tiles, T, slices)
+    ctx.sync()
+    got = Out.cpu().numpy()[:, :, :T]
+    ref = np.einsum("ncq,nqt->nct", A[:, :, :d].astype(np.float64), X[pix][:, :, :T].astype(np.float64))
+    err = np.abs(got - ref).max() / np.abs(ref).max()
+    assert err < 2e-6, (d, T, err)
+
+
+@pytest.mark.parametrize("d,T", [(400, 1000), (400, 77), (256, 320), (100, 64), (512, 200), (784, 130), (1024, 96), (1600, 70)])
+def test_tile_atx(gpu_ctx, d, T):
+    _atx_case(gpu_ctx, d, T, n_tiles=5, rows=max(2 * d, 900), slices=3)
+
+
+def test_tile_atx_consecutive_rows(gpu_ctx):
+    _atx_case(gpu_ctx, 100, 250, n_tiles=7, rows=700, slices=1, use_pix=False)
+
+
+def _xbt_case(ctx, d, T, n_tiles, rows, slices, shared_b=False, seed=1):
+    torch = _t()
+    lib = ctx.lib
+    rng = np.random.default_rng(seed)
+    ld = lib.pmd_time_ld(T)
+    s_ld = 16 * ((d + 15) // 16)
+    X = np.zeros((rows, ld), dtype=np.float32)
+    X[:, :T] = rng.standard_normal((rows, T)).astype(np.float32)
+    pix = np.stack([rng.choice(rows, size=d, replace=False) for _ in range(n_tiles)]).astype(np.int32)
+    nb = 1 if shared_b else n_tiles
+    B = np.zeros((nb, 64, ld), dtype=np.float32)
+    B[:, :50, :T] = rng.standard_normal((nb, 50, T)).astype(np.float32)
+    S = torch.full((n_tiles, slices, 64, s_ld), np.nan, dtype=torch.float32, device=ctx.device)
+    Xd, Bd, pd = dev(ctx, X), dev(ctx, B), dev(ctx, pix)
+    ctx.call("pmdk_tile_xbt", P(Xd), ld, P(pd), d, 0, d, P(Bd), 0 if shared_b else 64 * ld, ld, P(S), slices * 64 * s_ld,
+             64 * s_ld, s_ld, n_tiles, T, slices)
+    ctx.sync()
+    got = S.cpu().numpy().astype(np.float64).sum(axis=1)[:, :, :d]
+    Bu = np.broadcast_to(B, (n_tiles, 64, ld)) if shared_b else B
+    ref = np.einsum("nct,nqt->ncq", Bu[:, :, :T].astype(np.float64), X[pix][:, :, :T].astype(np.float64))
+    err = np.abs(got - ref).max() / np.abs(ref).max()
+    assert err < 2e-6, (d, T, err)
+    if s_ld > d:
+        pad = S.cpu().numpy()[:, :, :, d:s_ld]
+        assert np.all(pad == 0)
+
+
+@pytest.mark.parametrize("d,T,slices", [(400, 1000, 4), (400, 50, 1), (100, 333, 2), (256, 1000, 4), (1024, 100, 2), (1600, 48, 1)])
+def test_tile_xbt(gpu_ctx, d, T, slices):
+    _xbt_case(gpu_ctx, d, T, n_tiles=4, rows=max(2 * d, 800), slices=slices)
+
+
+def test_tile_xbt_shared_b(gpu_ctx):
+    _xbt_case(gpu_ctx, 256, 500, n_tiles=6, rows=2000, slices=4, shared_b=True)
+
+
+def test_tile_gram_and_rowmix(gpu_ctx):
+    torch = _t()
+    ctx = gpu_ctx
+    rng = np.random.default_rng(2)
+    n, T = 5, 1234
+    ld = ctx.lib.pmd_time_ld(T)
+    In = np.zeros((n, 64, ld), dtype=np.float32)
+    In[:, :50, :T] = rng.standard_normal((n, 50, T)).astype(np.float32) * np.logspace(0, 3, 50)[None, :, None].astype(np.float32)
+    G = torch.empty((n, 4, 64, 64), dtype=torch.float64, device=ctx.device)
+    Ind = dev(ctx, In)
+    ctx.call("pmdk_tile_gram", P(Ind), 64 * ld, ld, T, n, 4, P(G))
+    ctx.sync()
+    got = G.cpu().numpy().sum(axis=1)
+    ref = np.einsum("nit,njt->nij", In[:, :, :T].astype(np.float64), In[:, :, :T].astype(np.float64))
+    assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()
+    # rowmix, in place, fp64 accumulation
+    N = rng.standard_normal((n, 64, 64))
+    Nd = dev(ctx, N)
+    ctx.call("pmdk_tile_rowmix", P(Ind), 64 * ld, ld, P(Nd), 4096, 50, 37, P(Ind), 64 * ld, ld, T, n)
+    ctx.sync()
+    out = Ind.cpu().numpy()
+    ref = np.einsum("npc,npt->nct", N[:, :50, :37], In[:, :50, :T].astype(np.float64))
+    assert np.abs(out[:, :37, :T] - ref).max() / np.abs(ref).max() < 2e-7
+    assert np.all(out[:, 37:, :T] == 0)
+
+
+@pytest.mark.parametrize("Prow,l", [(100, 60), (100, 20), (25, 20), (400, 11), (256, 60), (400, 60)])
+def test_small_qr(gpu_ctx, Prow, l):
+    torch = _t()
+    ctx = gpu_ctx
+    rng = np.random.default_rng(3)
+    n = 6
+    ldy = 16 * ((Prow + 15) // 16)
+    Y = rng.standard_normal((n, Prow, l)).astype(np.float32)
+    # make two tiles rank deficient (the reference hits this whenever frames/avg_factor < rank + 10)
+    Y[0] = (rng.standard_normal((Prow, 5)) @ rng.standard_normal((5, l))).astype(np.float32)
+    Y[1, :, l // 2:] = 0
+    Yt = np.zeros((n, 64, ldy), dtype=np.float32)
+    Yt[:, :l, :Prow] = Y.transpose(0, 2, 1)
+    Qt = torch.zeros((n, 64, ldy), dtype=torch.float32, device=ctx.device)
+    Ytd = dev(ctx, Yt)
+    ctx.call("pmdk_small_qr", P(Ytd), 64 * ldy, ldy, Prow, l, P(Qt), 64 * ldy, ldy, n)
+    ctx.sync()
+    q = Qt.cpu().numpy()
+    nref = min(Prow, l)
+    for b in range(n):
+        Q = q[b, :nref, :Prow].T.astype(np.float64)
+        assert np.abs(Q.T @ Q - np.eye(nref)).max() < 5e-6, b
+        resid = Y[b].astype(np.float64) - Q @ (Q.T @ Y[b].astype(np.float64))
+        assert np.abs(resid).max() < 1e-4 * max(np.abs(Y[b]).max(), 1), b
+        if b >= 2:
+            Qn, _ = np.linalg.qr(Y[b].astype(np.float64))
+            # same columns up to sign
+            dots = np.abs(np.sum(Qn[:, :nref] * Q, axis=0))
+            assert np.all(dots > 1 - 1e-5), b
+    assert np.all(q[:, nref:, :] == 0)
+
+
+def test_small_eig(gpu_ctx):
+    torch = _t()
+    ctx = gpu_ctx
+    rng = np.random.default_rng(4)
+    n_t, n = 7, 50
+    G = np.zeros((n_t, 2, 64, 64))
+    mats = []
+    for b in range(n_t):
+        A = rng.standard_normal((n, 300)) * np.logspace(0, -4 if b else 0, n)[:, None]
+        if b == 1:
+            A[n - 5:] = 0  # null directions
+        M = A @ A.T
+        mats.append(M)
+        G[b, 0, :n, :n] = 0.25 * M
+        G[b, 1, :n, :n] = 0.75 * M
+    Gd = dev(ctx, G)
+    Nout = torch.empty((n_t, 64, 64), dtype=torch.float64, device=ctx.device)
+    lam = torch.empty((n_t, 64), dtype=torch.float64, device=ctx.device)
+    ctx.call("pmdk_small_eig", P(Gd), 2, n, 0, 0.0, P(Nout), P(lam), n_t)
+    ctx.sync()
+    V = Nout.cpu().numpy()
+    L = lam.cpu().numpy()
+    for b in range(n_t):
+        w = np.linalg.eigvalsh(mats[b])[::-1]
+        assert np.all(np.diff(L[b, :n]) <= 1e-9 * w[0])
+        np.testing.assert_allclose(L[b, :n], w, rtol=1e-9, atol=1e-12 * w[0])
+        Vb = V[b, :n, :n]
+        assert np.abs(Vb.T @ Vb - np.eye(n)).max() < 1e-12
+        assert np.abs(mats[b] @ Vb - Vb * L[b, :n][None, :]).max() < 1e-11 * w[0]
+    # mode 1: scaled columns, null guard
+    ctx.call("pmdk_small_eig", P(Gd), 2, n, 1, 1e-10, P(Nout), P(lam), n_t)
+    ctx.sync()
+    V1 = Nout.cpu().numpy()
+    b = 1
+    kept = L[b, :n] > 1e-10 * L[b, 0]
+    assert kept.sum() == n - 5
+    Nn = V1[b, :n, :n]
+    W = Nn.T @ mats[b] @ Nn
+    assert np.abs(W[np.ix_(kept, kept)] - np.eye(kept.sum())).max() < 1e-9
+    assert np.all(Nn[:, ~kept] == 0)
+
+
+def test_pool_bin(gpu_ctx):
+    torch = _t()
+    ctx = gpu_ctx
+    from localmd_amd import grid
+
+    rng = np.random.default_rng(5)
+    b1, b2, a, T = 20, 12, 10, 230
+    d1, d2 = 30, 26
+    ld = ctx.lib.pmd_time_ld(T)
+    X = np.zeros((d1 * d2, ld), dtype=np.float32)
+    X[:, :T] = rng.standard_normal((d1 * d2, T)).astype(np.float32)
+    it1, it2 = grid.tile_origins((d1, d2), (b1, b2))
+    pix, origins = grid.tile_pixel_lists((d1, d2), (b1, b2), it1, it2)
+    pool_q, pool_idx, pool_w, shp = grid.pooling_maps((b1, b2), 2)
+    n = pix.shape[0]
+    Pn = pool_q.shape[0]
+    nb = T // a
+    ldb = ctx.lib.pmd_time_ld(nb)
+    ab = torch.zeros((n, Pn, ldb), dtype=torch.float32, device=ctx.device)
+    Xd, pd, pq = dev(ctx, X), dev(ctx, pix), dev(ctx, pool_q)
+    ctx.call("pmdk_tile_pool_bin", P(Xd), ld, P(pd), n, b1 * b2, P(pq), pool_q.shape[1], Pn, a, nb, P(ab), ldb, Pn * ldb)
+    ctx.sync()
+    got = ab.cpu().numpy()[:, :, :nb]
+    mov = X[:, :T].reshape(d1, d2, T)
+    for t, (k, j) in enumerate(origins):
+        block = mov[k:k + b1, j:j + b2, : nb * a]
+        ds = O.downsample_average_pooling(block, 2)
+        ref = np.mean(np.reshape(ds, (ds.shape[0] * ds.shape[1], a, nb), order="F"), axis=1)
+        np.testing.assert_allclose(got[t], ref, rtol=0, atol=2e-6)
+
+
+def test_roughness_stats(gpu_ctx):
+    torch = _t()
+    ctx = gpu_ctx
+    rng = np.random.default_rng(6)
+    b1, b2, T, n, r = 20, 14, 777, 3, 9
+    d = b1 * b2
+    dpad = ctx.lib.pmd_tile_dpad(d)
+    ld = ctx.lib.pmd_time_ld(T)
+    Ut = np.zeros((n, 64, dpad), dtype=np.float32)
+    Ut[:, :r, :d] = rng.standard_normal((n, r, d)).astype(np.float32)
+    V = np.zeros((n, 64, ld), dtype=np.float32)
+    V[:, :r, :T] = np.cumsum(rng.standard_normal((n, r, T)), axis=2).astype(np.float32)
+    stats = torch.zeros((n, 64, 2), dtype=torch.float32, device=ctx.device)
+    Ud, Vd = dev(ctx, Ut), dev(ctx, V)
+    ctx.call("pmdk_roughness", P(Ud), 64 * dpad, dpad, b1, b2, P(Vd), 64 * ld, ld, T, r, P(stats), n)
+    ctx.sync()
+    got = stats.cpu().numpy()
+    for t in range(n):
+        for c in range(r):
+            img = Ut[t, c, :d].reshape((b1, b2), order="F")
+            sp = O.spatial_roughness_stat(img)
+            tp = O.temporal_roughness_stat(V[t, c, :T])
+            assert abs(got[t, c, 0] - sp) <= 3e-6 * abs(sp)
+            assert abs(got[t, c, 1] - tp) <= 3e-6 * abs(tp)
+
+
+def test_syevd_and_gemm(gpu_ctx):
+    torch = _t()
+    ctx = gpu_ctx
+    rng = np.random.default_rng(7)
+    n = 300
+    A = rng.standard_normal((n, n)).astype(np.float32)
+    S = (A @ A.T).astype(np.float32)
+    Sd = dev(ctx, S.copy())
+    w = torch.empty(n, dtype=torch.float32, device=ctx.device)
+    work = torch.empty(n, dtype=torch.float32, device=ctx.device)
+    info = torch.zeros(4, dtype=torch.int32, device=ctx.device)
+    ctx.call("pmdk_syevd", n, P(Sd), n, P(w), P(work), P(info))
+    ctx.sync()
+    assert int(info[0]) == 0
+    wv = w.cpu().numpy()
+    E = Sd.cpu().numpy()  # rows are eigenvectors
+    np.testing.assert_allclose(wv, np.linalg.eigvalsh(S.astype(np.float64)), rtol=2e-4, atol=1e-3)
+    assert np.abs(E @ S.astype(np.float64) - wv[:, None] * E).max() < 2e-3 * wv.max()
+    # row-major gemm with both transposes
+    Bm = rng.standard_normal((70, 50)).astype(np.float32)
+    Cm = rng.standard_normal((70, 30)).astype(np.float32)
+    out = torch.empty((50, 30), dtype=torch.float32, device=ctx.device)
+    ctx.call("pmd_gemm", 1, 0, 50, 30, 70, 1.0, P(dev(ctx, Bm)), 50, P(dev(ctx, Cm)), 30, 0.0, P(out), 30)
+    ctx.sync()
+    np.testing.assert_allclose(out.cpu().numpy(), Bm.T @ Cm, rtol=1e-4, atol=1e-4)
+    out2 = torch.empty((70, 70), dtype=torch.float32, device=ctx.device)
+    ctx.call("pmd_gemm", 0, 1, 70, 70, 50, 1.0, P(dev(ctx, Bm)), 50, P(dev(ctx, Bm)), 50, 0.0, P(out2), 70)
+    ctx.sync()
+    np.testing.assert_allclose(out2.cpu().numpy(), Bm @ Bm.T, rtol=1e-4, atol=1e-4)
