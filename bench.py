@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""
+Headline benchmark: frames/sec of the full PMD decomposition (BASELINE.json metric) on a
+synthetic 512x512x10000 fp32 movie, 20x20 blocks, reference-default arguments, movie resident
+in HBM when the clock starts, results (CSR U, R, s, Vt, mean, std) on the host when it stops.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config NAME] [--no-cpu-baseline]
+
+One "step" = one complete decomposition.  Rank 0 prints ONE JSON line carrying the metric,
+`roofline` (dominant hand-written kernel, timed with HIP events on its stream) and
+`cpu_baseline` (the CPU oracle timed on a bounded crop of the same movie, rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+CONFIGS = {
+    # name: (T, d1, d2, block, max_components)
+    "demo_60x80x2000": dict(T=2000, d1=60, d2=80, block=20, frames=100, max_components=50),
+    "256x256x2000_b20_r8": dict(T=2000, d1=256, d2=256, block=20, frames=2000, max_components=8),
+    "512x512x10000_b20": dict(T=10000, d1=512, d2=512, block=20, frames=10000, max_components=50),
+}
+DEFAULT_CONFIG = "512x512x10000_b20"
+FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, dense f32 matrix peak
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(cfg, movie_dev, seed):
+    """Oracle (oracle/pmd_oracle.py = NumPy port of the reference) on a bounded crop of the same
+    movie: a 60x60-pixel window, all frames, same arguments."""
+    from oracle import pmd_oracle as O, philox
+
+    try:
+        from threadpoolctl import threadpool_info
+
+        threads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    crop = 60
+    sub = movie_dev[:, :crop, :crop].cpu().numpy()
+    np.random.seed(0)
+    t0 = time.perf_counter()
+    O.localmd_decomposition(sub, (cfg["block"], cfg["block"]), cfg["frames"], max_components=cfg["max_components"],
+                            rng=philox.PhiloxSource(seed), sim_iters=5)
+    dt = time.perf_counter() - t0
+    scale = (cfg["d1"] * cfg["d2"]) / float(crop * crop)
+    value = cfg["T"] / (dt * scale)
+    return {
+        "value": value, "unit": "frames/s", "cores": int(threads), "kind": "port",
+        "sample": f"{crop}x{crop}x{cfg['T']} crop of the same movie ({dt:.1f} s of CPU work incl. 5 of the 250 threshold "
+                  f"simulations), scaled by pixel count x{scale:.1f} (extrapolated; global eigh cost not rescaled)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default=DEFAULT_CONFIG, choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+
+    import localmd_amd
+    from localmd_amd import decomposition as Dm
+    from localmd_amd._lib import Context
+    from localmd_amd.synthetic import make_movie_torch
+
+    Dm.QUIET = True
+    cfg = CONFIGS[args.config]
+    device = torch.device("cuda", local_rank)
+    movie = make_movie_torch(cfg["T"], cfg["d1"], cfg["d2"], device, seed=0)
+    ctx = Context(local_rank)
+    seed = 2024
+
+    def one_step(diag=False):
+        np.random.seed(0)
+        return localmd_amd.localmd_decomposition(
+            movie, (cfg["block"], cfg["block"]), cfg["frames"], max_components=cfg["max_components"], seed=seed,
+            ctx=ctx, return_diagnostics=diag)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    barrier()
+    ctx.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.profile_summary()
+    ctx.profile_enable(False)
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # one extra, untimed, instrumented run for the per-phase breakdown and the tile statistics
+    _, diag = one_step(diag=True)
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * cfg["T"] * args.steps / elapsed if world > 1 else cfg["T"] * args.steps / elapsed
+
+    # roofline of the dominant hand-written kernel: tile_atx (four launches per step: V_ds = U_ds^T X,
+    # W = U0^T X, the sketch Q^T A and the full-movie projection U^T X).  Algorithmic work per launch
+    # (DESIGN.md): flops = 2 * r * d * T per tile with r = max_components (not the padded 64 rows).
+    n_tiles = len(diag["tile_ranks"])
+    d = cfg["block"] ** 2
+    r = diag["max_components"]
+    crop = diag["crop"]
+    atx_ms, atx_n = prof.get("tile_atx", (0.0, 0))
+    big_launches = 3 * args.steps  # the three d x T passes; the (P x T/10) sketch pass is <1% of the flops
+    flops_per_launch = 2.0 * r * d * crop * n_tiles
+    bytes_per_launch = 4.0 * d * crop * n_tiles
+    avg_ms = atx_ms / max(big_launches, 1)
+    achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+    roofline = {
+        "kernel": "tile_atx (v_mfma_f32_16x16x4_f32)", "bound": "mfma", "achieved": achieved,
+        "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+        "avg_launch_ms": avg_ms, "launches_timed": atx_n, "algorithmic_gflop_per_launch": flops_per_launch / 1e9,
+        "algorithmic_gb_per_launch": bytes_per_launch / 1e9,
+        "hbm_gbs_equiv": bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
+    }
+    out = {
+        "metric": "frames/sec PMD decomposition", "value": value, "unit": "frames/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "weak" if world > 1 else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": args.config, "fov": [cfg["d1"], cfg["d2"]], "frames": cfg["T"], "block": cfg["block"],
+                   "frames_to_init": cfg["frames"], "max_components": cfg["max_components"], "tiles": n_tiles,
+                   "rank_before": diag["rank_before"], "rank_after": diag["rank_after"],
+                   "mean_tile_rank": float(np.mean(diag["tile_ranks"])),
+                   "parallelism": "1 process per GPU" + (", independent replicas" if world > 1 else "")},
+        "roofline": roofline,
+        "phases_ms": {k: 1e3 * v for k, v in diag["timings"].items()},
+        "kernel_ms_per_step": {k: v[0] / args.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg, movie, seed)
+        out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    main()

@@ -42,6 +42,13 @@ int pmd_ctx_set_stream(pmd_ctx* ctx, void* hip_stream);
 int pmd_ctx_sync(pmd_ctx* ctx);
 const char* pmd_last_error(pmd_ctx* ctx);
 
+/* Measurement: HIP events on the context's stream around every kernel group (bench.py's
+ * roofline figures).  pmd_profile_enable(ctx, 1) resets and starts; pmd_profile_query sums the
+ * durations of the groups called `name`; pmd_profile_names lists the names seen. */
+int pmd_profile_enable(pmd_ctx* ctx, int on);
+int pmd_profile_query(pmd_ctx* ctx, const char* name, double* total_ms, int* count);
+int pmd_profile_names(pmd_ctx* ctx, char* buf, int cap);
+
 /* padded sizes every caller needs to allocate buffers */
 int pmd_tile_dpad(int d);       /* padded pixel count of a d-pixel tile (-1: unsupported)   */
 long pmd_time_ld(long t);       /* leading dimension of a time-contiguous row of t frames   */

@@ -21,6 +21,9 @@ SIGNATURES = {
     "pmd_ctx_set_stream": (c_i, [c_p, c_p]),
     "pmd_ctx_sync": (c_i, [c_p]),
     "pmd_last_error": (C.c_char_p, [c_p]),
+    "pmd_profile_enable": (c_i, [c_p, c_i]),
+    "pmd_profile_query": (c_i, [c_p, C.c_char_p, C.POINTER(c_d), C.POINTER(c_i)]),
+    "pmd_profile_names": (c_i, [c_p, C.c_char_p, c_i]),
     "pmd_tile_dpad": (c_i, [c_i]),
     "pmd_time_ld": (c_l, [c_l]),
     "pmd_rng_normal": (c_i, [c_p, c_u64, c_u32, c_u32, c_u32, c_i, c_l, c_i, c_i, c_p, c_l, c_l]),
@@ -128,6 +131,22 @@ class Context:
 
     def sync(self):
         self.call("pmd_ctx_sync")
+
+    def profile_enable(self, on=True):
+        self.call("pmd_profile_enable", 1 if on else 0)
+
+    def profile_summary(self):
+        """{kernel group: (total ms, launches)} measured with HIP events since profile_enable."""
+        buf = C.create_string_buffer(4096)
+        self.call("pmd_profile_names", buf, 4096)
+        out = {}
+        for name in buf.value.decode().split("\n"):
+            if not name:
+                continue
+            ms, cnt = c_d(0), c_i(0)
+            self.call("pmd_profile_query", name.encode(), C.byref(ms), C.byref(cnt))
+            out[name] = (ms.value, cnt.value)
+        return out
 
     def workspace(self, nbytes):
         """A reusable device scratch buffer of at least nbytes (uint8 tensor)."""

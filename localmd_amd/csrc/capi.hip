@@ -21,6 +21,7 @@ int pmd_ctx_create(int device, void* hip_stream, pmd_ctx** out) {
   ctx->tables = nullptr;
   ctx->blas = nullptr;
   ctx->err[0] = 0;
+  ctx->profile = false;
   if (rocblas_create_handle(&ctx->blas) != rocblas_status_success) { delete ctx; return PMD_ERR_BLAS; }
   rocblas_set_stream(ctx->blas, ctx->stream);
   rocblas_set_pointer_mode(ctx->blas, rocblas_pointer_mode_host);
@@ -52,6 +53,51 @@ int pmd_ctx_sync(pmd_ctx* ctx) {
 }
 
 const char* pmd_last_error(pmd_ctx* ctx) { return ctx ? ctx->err : "null context"; }
+
+int pmd_profile_enable(pmd_ctx* ctx, int on) {
+  CTX_CHECK(ctx);
+  for (auto& r : ctx->recs) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
+  ctx->recs.clear();
+  ctx->profile = on != 0;
+  return PMD_OK;
+}
+
+// Sum of the event-timed durations of every launch group called `name` since the last
+// pmd_profile_enable (synchronises the stream).  total_ms/count may be NULL.
+int pmd_profile_query(pmd_ctx* ctx, const char* name, double* total_ms, int* count) {
+  CTX_CHECK(ctx);
+  PMD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  double tot = 0.0;
+  int n = 0;
+  for (auto& r : ctx->recs) {
+    if (strcmp(r.name, name) != 0) continue;
+    float ms = 0.f;
+    PMD_HIP(ctx, hipEventElapsedTime(&ms, r.start, r.stop));
+    tot += ms;
+    n++;
+  }
+  if (total_ms) *total_ms = tot;
+  if (count) *count = n;
+  return PMD_OK;
+}
+
+// Names seen so far, '\n'-separated, written into buf (truncated to cap-1 characters).
+int pmd_profile_names(pmd_ctx* ctx, char* buf, int cap) {
+  CTX_CHECK(ctx);
+  if (!buf || cap < 1) return PMD_ERR_ARG;
+  buf[0] = 0;
+  std::vector<const char*> seen;
+  for (auto& r : ctx->recs) {
+    bool dup = false;
+    for (auto s : seen) dup = dup || strcmp(s, r.name) == 0;
+    if (dup) continue;
+    seen.push_back(r.name);
+    if ((int)(strlen(buf) + strlen(r.name) + 2) >= cap) break;
+    strcat(buf, r.name);
+    strcat(buf, "\n");
+  }
+  return PMD_OK;
+}
 
 int pmd_rng_normal(pmd_ctx* ctx, uint64_t seed, uint32_t stream, uint32_t index0, uint32_t index_step, int batch,
                    long rows, int cols, int transpose, float* out, long ld, long batch_stride) {

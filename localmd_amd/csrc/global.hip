@@ -24,6 +24,7 @@
 // row-major C(m x n) = alpha * op(A) * op(B) + beta * C
 int pmd_gemm_rm(pmd_ctx* ctx, int transA, int transB, int m, int n, int k, float alpha, const float* A, long lda,
                 const float* B, long ldb, float beta, float* C, long ldc) {
+  pmd_prof_scope prof__(ctx, "rocblas_sgemm");
   if (m <= 0 || n <= 0) return PMD_OK;
   PMD_BLAS(ctx, rocblas_sgemm(ctx->blas, transB ? rocblas_operation_transpose : rocblas_operation_none,
                               transA ? rocblas_operation_transpose : rocblas_operation_none, n, m, k, &alpha, B,
@@ -34,6 +35,7 @@ int pmd_gemm_rm(pmd_ctx* ctx, int transA, int transB, int m, int n, int k, float
 // symmetric eigendecomposition, ascending eigenvalues; on exit row j of A is eigenvector j.
 // work: n floats, info: device int.
 int pmd_syevd(pmd_ctx* ctx, int n, float* A, long lda, float* w, float* work, int* info) {
+  pmd_prof_scope prof__(ctx, "rocsolver_ssyevd");
   PMD_BLAS(ctx, rocsolver_ssyevd(ctx->blas, rocblas_evect_original, rocblas_fill_upper, n, A, (rocblas_int)lda, w, work, info));
   return PMD_OK;
 }
@@ -46,16 +48,18 @@ __global__ void weight_tiles_kernel(const float* __restrict__ Ut, long tile_stri
                                     const int* __restrict__ ranks, float* __restrict__ Uw) {
   const int tile = blockIdx.y;
   const int rk = ranks[tile];
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < PMD_RPAD * d; i += gridDim.x * blockDim.x) {
-    const int c = i / d, q = i - c * d;
+  // every one of the 64 x ld entries is written: the padding feeds MFMA operands (0 * x must be 0)
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < PMD_RPAD * ld; i += gridDim.x * blockDim.x) {
+    const int c = i / ld, q = i - c * ld;
     float v = 0.f;
-    if (c < rk) v = Ut[(long)tile * tile_stride + (long)c * ld + q] * w[q] / cumw[pix[(long)tile * d + q]];
+    if (c < rk && q < d) v = Ut[(long)tile * tile_stride + (long)c * ld + q] * w[q] / cumw[pix[(long)tile * d + q]];
     Uw[(long)tile * tile_stride + (long)c * ld + q] = v;
   }
 }
 
 int pmd_launch_weight_tiles(pmd_ctx* ctx, const float* Ut, int dpad, const int* pix, int d, const float* w,
                             const float* cumw, const int* ranks, float* Uw, int n_tiles) {
+  pmd_prof_scope prof__(ctx, "weight_tiles");
   for (int t0 = 0; t0 < n_tiles; t0 += 32768) {
     const int tn = (n_tiles - t0 < 32768) ? n_tiles - t0 : 32768;
     hipLaunchKernelGGL(weight_tiles_kernel, dim3(32, tn), dim3(256), 0, ctx->stream, Ut + (long)t0 * 64 * dpad,
@@ -79,6 +83,7 @@ __global__ void compact_rows_kernel(const float* __restrict__ Out, long tile_str
 
 int pmd_launch_compact_rows(pmd_ctx* ctx, const float* Out, long tile_stride, long ldo, const int* col_off,
                             const int* ranks, int T, float* Z, long ldz, int n_tiles) {
+  pmd_prof_scope prof__(ctx, "compact_rows");
   for (int t0 = 0; t0 < n_tiles; t0 += 32768) {
     const int tn = (n_tiles - t0 < 32768) ? n_tiles - t0 : 32768;
     hipLaunchKernelGGL(compact_rows_kernel, dim3(16, tn), dim3(256), 0, ctx->stream, Out + (long)t0 * tile_stride,
@@ -194,6 +199,7 @@ __global__ __launch_bounds__(256) void gram_bgbg_kernel(const float* __restrict_
 int pmd_gram_u_impl(pmd_ctx* ctx, const float* Uw, int dpad, int b1, int b2, const int* pix, const int* pairs,
                     int n_pairs, const int* origins, const int* col_off, const int* ranks, int n_tiles, int Rt,
                     const float* basis, long D, int K, float* G, long ldg) {
+  pmd_prof_scope prof__(ctx, "gram_u");
   const long R = Rt + K;
   PMD_HIP(ctx, hipMemsetAsync(G, 0, (size_t)R * ldg * sizeof(float), ctx->stream));
   if (n_pairs > 0) {

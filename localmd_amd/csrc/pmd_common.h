@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <vector>
 
 #define PMD_OK 0
 #define PMD_ERR_HIP -1
@@ -23,12 +24,37 @@
 #define PMD_STREAM_TILE_OMEGA 4
 #define PMD_STREAM_PRUNE 5
 
+struct pmd_prof_rec {
+  const char* name;
+  hipEvent_t start, stop;
+};
+
 struct pmd_ctx {
   int device;
   hipStream_t stream;
   rocblas_handle blas;
   float* tables;  // device: Hann window + FFT twiddles, see prep.hip
   char err[512];
+  bool profile;                      // pmd_profile_enable: HIP events around every kernel group
+  std::vector<pmd_prof_rec> recs;
+};
+
+// RAII: records a start/stop event pair on the context's stream around one launcher call
+struct pmd_prof_scope {
+  pmd_ctx* ctx;
+  pmd_prof_rec rec;
+  bool on;
+  pmd_prof_scope(pmd_ctx* c, const char* name) : ctx(c), on(c && c->profile) {
+    if (!on) return;
+    rec.name = name;
+    if (hipEventCreate(&rec.start) != hipSuccess || hipEventCreate(&rec.stop) != hipSuccess) { on = false; return; }
+    (void)hipEventRecord(rec.start, ctx->stream);
+  }
+  ~pmd_prof_scope() {
+    if (!on) return;
+    (void)hipEventRecord(rec.stop, ctx->stream);
+    ctx->recs.push_back(rec);
+  }
 };
 
 static inline int pmd_fail(pmd_ctx* ctx, int code, const char* what, const char* detail) {

@@ -143,6 +143,7 @@ size_t pmd_stats_workspace_bytes(int T, long D, int frame_const) {
 
 int pmd_launch_stats(pmd_ctx* ctx, const float* movie, int T, long D, int frame_const, int do_noise, float* mean_out,
                      float* std_out, void* ws, size_t ws_bytes) {
+  pmd_prof_scope prof__(ctx, "stats_welch");
   const int nchunks = (T + frame_const - 1) / frame_const;
   pmd_arena ar(ws, ws_bytes);
   double* csum = ar.take_n<double>((size_t)nchunks * D);
@@ -199,6 +200,7 @@ __global__ __launch_bounds__(256) void standardize_transpose_kernel(const float*
 
 int pmd_launch_standardize_transpose(pmd_ctx* ctx, const float* movie, long D, const int* frames, int nf,
                                      const float* mean, const float* stdv, float* out, long ld) {
+  pmd_prof_scope prof__(ctx, "standardize_transpose");
   dim3 grid((unsigned)((D + 63) / 64), (unsigned)((ld + 63) / 64));
   hipLaunchKernelGGL(standardize_transpose_kernel, grid, dim3(256), 0, ctx->stream, movie, D, frames, nf, mean, stdv,
                      out, ld);
@@ -227,6 +229,7 @@ __global__ __launch_bounds__(256) void filter_kernel(const float* __restrict__ i
 
 int pmd_launch_filter(pmd_ctx* ctx, const float* in, float* out, long D, int nf, long ld, const float* basis, int K,
                       const float* pj, long ldp) {
+  pmd_prof_scope prof__(ctx, "bg_filter");
   if (K > 64) return pmd_fail(ctx, PMD_ERR_UNSUPPORTED, "pmd_filter", "background rank > 64");
   int bx = (nf + 255) / 256;
   if (bx > 8) bx = 8;
@@ -292,6 +295,7 @@ __global__ __launch_bounds__(256) void tile_pool_bin_kernel(const float* __restr
 int pmd_launch_tile_pool_bin(pmd_ctx* ctx, const float* X, long ldx, const int* pix, int n_tiles, int d,
                              const int* pool_q, int pool_max, int P, int a, int nbins, float* abar, long ld_ab,
                              long tile_stride) {
+  pmd_prof_scope prof__(ctx, "tile_pool_bin");
   int bx = (nbins + 255) / 256;
   for (int t0 = 0; t0 < n_tiles; t0 += 32768) {
     const int tn = (n_tiles - t0 < 32768) ? n_tiles - t0 : 32768;

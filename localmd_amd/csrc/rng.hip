@@ -67,6 +67,7 @@ __global__ void rng_normal_kernel(uint64_t seed, uint32_t stream, uint32_t index
 
 int pmd_launch_rng(pmd_ctx* ctx, uint64_t seed, uint32_t stream, uint32_t index0, uint32_t index_step, int batch,
                    long rows, int cols, int transpose, float* out, long ld, long batch_stride) {
+  pmd_prof_scope prof__(ctx, "rng_normal");
   if (batch <= 0 || rows <= 0 || cols <= 0) return PMD_OK;
   const long nq = (rows * cols + 3) / 4;
   int bx = (int)((nq + 255) / 256);

@@ -105,6 +105,7 @@ __global__ __launch_bounds__(256) void small_qr_kernel(const float* __restrict__
 
 int pmd_launch_small_qr(pmd_ctx* ctx, const float* Yt, long y_tile_stride, int y_ld, int P, int l, float* Qt,
                         long q_tile_stride, int q_ld, int n_tiles) {
+  pmd_prof_scope prof__(ctx, "small_qr");
   if (n_tiles <= 0) return PMD_OK;
   if (l > 64) return pmd_fail(ctx, PMD_ERR_UNSUPPORTED, "small_qr", "more than 64 columns");
   const int ldm = P | 1;
@@ -243,6 +244,7 @@ __global__ __launch_bounds__(256) void small_eig_kernel(const double* __restrict
 
 int pmd_launch_small_eig(pmd_ctx* ctx, const double* G, int slices, int n, int mode, double tol, double* Nout,
                          double* lam_out, int n_tiles) {
+  pmd_prof_scope prof__(ctx, "small_eig");
   if (n_tiles <= 0) return PMD_OK;
   if (n > 64 || n < 1) return pmd_fail(ctx, PMD_ERR_UNSUPPORTED, "small_eig", "n must be in [1, 64]");
   const size_t bytes = (size_t)2 * 64 * EIG_LD * sizeof(double) + 64 * sizeof(double) + (64 + 2 + 64) * sizeof(int) + 64;
@@ -269,6 +271,7 @@ __global__ void expand_pooled_kernel(const float* __restrict__ In, long in_tile_
 int pmd_launch_expand_pooled(pmd_ctx* ctx, const float* In, long in_tile_stride, int in_ld, const int* pool_idx,
                              const float* pool_w, int d, int r, float* Out, long out_tile_stride, int out_ld,
                              int n_tiles) {
+  pmd_prof_scope prof__(ctx, "expand_pooled");
   int bx = (r * d + 255) / 256;
   if (bx > 32) bx = 32;
   for (int t0 = 0; t0 < n_tiles; t0 += 32768) {
@@ -335,6 +338,7 @@ __global__ __launch_bounds__(256) void temporal_stat_kernel(const float* __restr
 int pmd_launch_stats_roughness(pmd_ctx* ctx, const float* Ut, long u_tile_stride, int u_ld, int b1, int b2,
                                const float* V, long v_tile_stride, long v_ld, int T, int r, float* stats,
                                int n_tiles) {
+  pmd_prof_scope prof__(ctx, "roughness");
   for (int t0 = 0; t0 < n_tiles; t0 += 32768) {
     const int tn = (n_tiles - t0 < 32768) ? n_tiles - t0 : 32768;
     if (Ut) {
@@ -384,6 +388,7 @@ __global__ void decide_kernel(const float* __restrict__ stats, int r, float thr_
 
 int pmd_launch_decide(pmd_ctx* ctx, const float* stats, int r, float thr_s, float thr_t, int max_fail, int cap,
                       int n_tiles, int* good, int* keep, int* ranks) {
+  pmd_prof_scope prof__(ctx, "decide");
   hipLaunchKernelGGL(decide_kernel, dim3((n_tiles + 63) / 64), dim3(64), 0, ctx->stream, stats, r, thr_s, thr_t,
                      max_fail, cap, n_tiles, good, keep, ranks);
   PMD_LAUNCH_CHECK(ctx, "decide_kernel");

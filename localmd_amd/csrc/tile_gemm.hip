@@ -165,6 +165,7 @@ static int launch_atx_variant(pmd_ctx* ctx, const float* X, long ldx, const int*
 int pmd_launch_tile_atx(pmd_ctx* ctx, const float* X, long ldx, const int* pix, int pix_stride, long row0_stride, int d,
                         const float* A, long a_tile_stride, int a_ld, float* Out, long out_tile_stride, long ldo,
                         int n_tiles, int T, int slices) {
+  pmd_prof_scope prof__(ctx, "tile_atx");
   if (n_tiles <= 0 || T <= 0) return PMD_OK;
   int kz = 1;
   int dv = d;
@@ -279,6 +280,7 @@ __global__ __launch_bounds__(256) void tile_xbt_kernel(const float* __restrict__
 int pmd_launch_tile_xbt(pmd_ctx* ctx, const float* X, long ldx, const int* pix, int pix_stride, long row0_stride, int d,
                         const float* B, long b_tile_stride, long ldb, float* S, long s_tile_stride,
                         long s_slice_stride, int s_ld, int n_tiles, int T, int slices) {
+  pmd_prof_scope prof__(ctx, "tile_xbt");
   if (n_tiles <= 0 || T <= 0) return PMD_OK;
   const int n_groups = (T + 15) / 16;
   if (slices < 1) slices = 1;
@@ -341,6 +343,7 @@ __global__ __launch_bounds__(256) void tile_gram_kernel(const float* __restrict_
 // G: [tile][slices][64][64] doubles, g_tile_stride = slices*4096.
 int pmd_launch_tile_gram(pmd_ctx* ctx, const float* In, long tile_stride, long ld, int len, int n_tiles, int slices,
                          double* G) {
+  pmd_prof_scope prof__(ctx, "tile_gram");
   if (n_tiles <= 0) return PMD_OK;
   if (slices < 1) slices = 1;
   int cps = (len + slices - 1) / slices;
@@ -366,6 +369,7 @@ __global__ void reduce_slices_kernel(const float* __restrict__ in, long tile_str
 
 int pmd_launch_reduce_slices(pmd_ctx* ctx, const float* in, long tile_stride, long slice_stride, int slices, long n,
                              float* out, long out_tile_stride, int n_tiles) {
+  pmd_prof_scope prof__(ctx, "reduce_slices");
   int bx = (int)((n + 255) / 256);
   if (bx > 64) bx = 64;
   for (int t0 = 0; t0 < n_tiles; t0 += 32768) {
@@ -415,6 +419,7 @@ __global__ __launch_bounds__(256) void tile_rowmix_kernel(const float* __restric
 int pmd_launch_tile_rowmix(pmd_ctx* ctx, const float* In, long in_tile_stride, long ld_in, const double* N,
                            long n_tile_stride, int n_in, int n_out, float* Out, long out_tile_stride, long ld_out,
                            int len, int n_tiles) {
+  pmd_prof_scope prof__(ctx, "tile_rowmix");
   if (n_tiles <= 0 || len <= 0) return PMD_OK;
   int bx = (len + 255) / 256;
   if (bx > 64) bx = 64;

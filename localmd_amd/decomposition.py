@@ -57,6 +57,19 @@ def _round_up(x, m):
     return (x + m - 1) // m * m
 
 
+def _dbg(name, t):
+    """PMD_DEBUG=1: synchronise and report range / finiteness of an intermediate tensor."""
+    import os
+
+    if not os.environ.get("PMD_DEBUG"):
+        return
+    torch = _torch()
+    torch.cuda.synchronize()
+    tf = t.float() if t.dtype != torch.float64 else t
+    finite = bool(torch.isfinite(tf).all())
+    print(f"[pmd-debug] {name}: shape={tuple(t.shape)} finite={finite} absmax={float(tf.abs().max()):.4g}", flush=True)
+
+
 class _Movie:
     """The (T, D) float32 movie resident in HBM, plus the pixel-major standardised copies."""
 
@@ -390,6 +403,7 @@ def localmd_decomposition(
                  ptr(keep_dev), ptr(ranks_dev), ptr(lam_dev), ptr(ws), ws.numel())
         ctx.sync()
         lap("tiles", t0)
+        _dbg("ut", ut_dev); _dbg("v_tiles", v_dev[:, :, :crop]); _dbg("tile_lambda", lam_dev)
 
         # ---- sparse assembly (decomposition.py:752-857) on the host: integers + float64 scaling
         t0 = time.perf_counter()
@@ -450,9 +464,11 @@ def localmd_decomposition(
             ctx.call("pmd_gemm", 0, 0, Rc, n_rand, crop, 1.0, ptr(vc), m_cols, ptr(rand), n_rand, 0.0, ptr(right), n_rand)
             m_cols = n_rand
         use_right = R > m_cols  # decomposition.py:976 (R counts the placeholder column too)
+        _dbg("G", G); _dbg("v_cropped", vc)
         P_dev, rp = _orthogonalize(ctx, G, Rc, right if use_right else None, m_cols, m_cols)
         ldp = P_dev.shape[1]
         display("After performing rank reduction, the updated rank is {}".format(rp))
+        _dbg("P", P_dev[:, :rp])
         del G
         lap("orthogonalize", t0)
 
@@ -477,6 +493,7 @@ def localmd_decomposition(
                 Z[Rt:Rt + K, :] = pj_full[:, :T]
         Vp = torch.empty((rp, T), dtype=torch.float32, device=ctx.device)
         ctx.call("pmd_gemm", 1, 0, rp, T, Rc, 1.0, ptr(P_dev), ldp, ptr(Z), T, 0.0, ptr(Vp), T)
+        _dbg("Z", Z); _dbg("Vp", Vp)
         lap("v_projection", t0)
 
         # ---- final SVD (decomposition.py:894-904)

@@ -304,10 +304,11 @@ def test_syevd_and_gemm(gpu_ctx):
     Bm = rng.standard_normal((70, 50)).astype(np.float32)
     Cm = rng.standard_normal((70, 30)).astype(np.float32)
     out = torch.empty((50, 30), dtype=torch.float32, device=ctx.device)
-    ctx.call("pmd_gemm", 1, 0, 50, 30, 70, 1.0, P(dev(ctx, Bm)), 50, P(dev(ctx, Cm)), 30, 0.0, P(out), 30)
+    Bd, Cd = dev(ctx, Bm), dev(ctx, Cm)  # keep the tensors alive until the call has run
+    ctx.call("pmd_gemm", 1, 0, 50, 30, 70, 1.0, P(Bd), 50, P(Cd), 30, 0.0, P(out), 30)
     ctx.sync()
     np.testing.assert_allclose(out.cpu().numpy(), Bm.T @ Cm, rtol=1e-4, atol=1e-4)
     out2 = torch.empty((70, 70), dtype=torch.float32, device=ctx.device)
-    ctx.call("pmd_gemm", 0, 1, 70, 70, 50, 1.0, P(dev(ctx, Bm)), 50, P(dev(ctx, Bm)), 50, 0.0, P(out2), 70)
+    ctx.call("pmd_gemm", 0, 1, 70, 70, 50, 1.0, P(Bd), 50, P(Bd), 50, 0.0, P(out2), 70)
     ctx.sync()
     np.testing.assert_allclose(out2.cpu().numpy(), Bm @ Bm.T, rtol=1e-4, atol=1e-4)

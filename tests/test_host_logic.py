@@ -1,0 +1,278 @@
+"""
+CPU tests of the host side: tile-grid integers, pooling maps, sparse assembly, PMDArray /
+.npz layout, dataset boundary, TIFF reader, and the C-ABI surface of libpmd_hip.so (symbols
+only -- no compute call is possible without a GPU, and the product must fail loudly then).
+"""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import scipy.sparse
+
+import localmd_amd
+from localmd_amd import grid
+from localmd_amd import _lib
+from oracle import pmd_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------ grid / integers ----------
+@pytest.mark.parametrize("fov,blk", [((512, 512), (20, 20)), ((150, 150), (28, 40)), ((60, 80), (20, 20)),
+                                     ((33, 47), (20, 16)), ((20, 20), (20, 20)), ((2048, 64), (16, 16))])
+def test_tile_grid_weights_match_oracle(fov, blk):
+    assert grid.tile_origins(fov, blk) == O.tile_grid(fov, blk)
+    np.testing.assert_array_equal(grid.block_weight_matrix(blk), O.block_weight_matrix(blk))
+    it1, it2 = grid.tile_origins(fov, blk)
+    pix, origins = grid.tile_pixel_lists(fov, blk, it1, it2)
+    assert pix.shape == (len(it1) * len(it2), blk[0] * blk[1])
+    # tile order k-outer / j-inner, q = il + b1*jl
+    t = len(it2) + 1 if len(it1) > 1 and len(it2) > 1 else 0
+    k, j = origins[t]
+    assert (k, j) == (it1[t // len(it2)], it2[t % len(it2)])
+    q = 3 + blk[0] * 2
+    assert pix[t, q] == (k + 3) * fov[1] + (j + 2)
+    # weights: partition of unity after normalisation
+    bw = grid.block_weight_matrix(blk)
+    cw = grid.cumulative_weights(fov, blk, origins, bw)
+    assert cw.min() >= 1
+    acc = np.zeros(fov)
+    for (k, j) in origins:
+        acc[k:k + blk[0], j:j + blk[1]] += bw / cw[k:k + blk[0], j:j + blk[1]]
+    np.testing.assert_allclose(acc, 1.0, atol=1e-12)
+
+
+def test_validation_errors():
+    with pytest.raises(ValueError):
+        grid.check_fov_size((9, 50))
+    with pytest.raises(ValueError):
+        grid.update_block_sizes((8, 20), (100, 100))
+    assert grid.update_block_sizes((40, 20), (30, 100)) == [30, 20]
+    with pytest.raises(ValueError):
+        grid.block_weight_matrix((21, 20))
+    with pytest.raises(ValueError):
+        grid.identify_window_chunks(200, 100, 50)
+    with pytest.raises(ValueError):
+        grid.identify_window_chunks(100, 200, 150)
+    np.random.seed(5)
+    a = grid.identify_window_chunks(300, 1000, 100)
+    np.random.seed(5)
+    b = O.identify_window_chunks(300, 1000, 100)
+    assert a == b and len(a) == 300
+
+
+@pytest.mark.parametrize("blk,n", [((20, 20), 2), ((20, 16), 2), ((10, 14), 3), ((20, 20), 1)])
+def test_pooling_maps_match_reduce_window(blk, n):
+    pool_q, pool_idx, pool_w, shp = grid.pooling_maps(blk, n)
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((blk[0], blk[1], 3)).astype(np.float32)
+    ref = O.downsample_average_pooling(x, n)
+    assert ref.shape[:2] == shp
+    flat = x.reshape((blk[0] * blk[1], 3), order="F")
+    got = np.zeros((pool_q.shape[0], 3))
+    for p in range(pool_q.shape[0]):
+        members = pool_q[p][pool_q[p] >= 0]
+        got[p] = flat[members].mean(axis=0)
+        assert np.all(pool_idx[members] == p)
+        np.testing.assert_allclose(pool_w[members], 1.0 / len(members))
+    np.testing.assert_allclose(got, ref.reshape((-1, 3), order="F"), atol=1e-6)
+
+
+def test_overlap_pairs_cover_exactly_the_intersections():
+    fov, blk = (50, 46), (20, 20)
+    it1, it2 = grid.tile_origins(fov, blk)
+    pix, origins = grid.tile_pixel_lists(fov, blk, it1, it2)
+    pairs = grid.overlap_pairs(origins, blk)
+    masks = []
+    for (k, j) in origins:
+        m = np.zeros(fov, dtype=bool)
+        m[k:k + 20, j:j + 20] = True
+        masks.append(m)
+    seen = set()
+    for a, b, i0, i1, j0, j1 in pairs:
+        inter = masks[a] & masks[b]
+        rect = np.zeros(fov, dtype=bool)
+        rect[i0:i1, j0:j1] = True
+        assert a <= b and np.array_equal(inter, rect) and inter.any()
+        seen.add((a, b))
+    for a in range(len(origins)):
+        for b in range(a, len(origins)):
+            assert ((masks[a] & masks[b]).any()) == ((a, b) in seen)
+
+
+def test_sparse_assembly_is_bitwise_the_reference_construction():
+    from localmd_amd.decomposition import _sparse_u
+    from scipy.sparse import coo_matrix, diags
+
+    rng = np.random.default_rng(0)
+    for order in ("F", "C"):
+        d1, d2, b = 50, 46, 20
+        it1, it2 = grid.tile_origins((d1, d2), (b, b))
+        pix, origins = grid.tile_pixel_lists((d1, d2), (b, b), it1, it2)
+        n = pix.shape[0]
+        ranks = rng.integers(0, 5, n)
+        ut = np.zeros((n, 64, 400), dtype=np.float32)
+        for t in range(n):
+            ut[t, :ranks[t], :] = rng.standard_normal((ranks[t], 400)).astype(np.float32)
+        ut[1, 0, 5] = 0.0  # an exact zero must be dropped like dia.dot(coo) does
+        bw = grid.block_weight_matrix((b, b))
+        fov = np.arange(d1 * d2).reshape((d1, d2), order=order)
+        cumw = grid.cumulative_weights((d1, d2), (b, b), origins, bw)
+        inv = np.zeros(d1 * d2)
+        inv[fov.reshape(-1)] = 1 / cumw.reshape(-1)
+        mine, off = _sparse_u(ut, ranks, fov.reshape(-1)[pix], bw, inv, d1 * d2)
+        # the reference's construction (decomposition.py:812-853), literally
+        rows_l, cols_l, vals_l, col, cw = [], [], [], 0, np.zeros((d1, d2))
+        for t, (k, j) in enumerate(origins):
+            sp = ut[t, :ranks[t], :].T.reshape((b, b, ranks[t]), order="F").astype(np.float64) * bw[:, :, None]
+            cw[k:k + b, j:j + b] += bw
+            ridx = fov[k:k + b, j:j + b][:, :, None] + np.zeros((1, 1, ranks[t]))
+            cidx = np.zeros_like(ridx) + np.arange(col, col + ranks[t])[None, None, :]
+            rows_l += ridx.flatten().tolist()
+            cols_l += cidx.flatten().tolist()
+            vals_l += sp.flatten().tolist()
+            col += ranks[t]
+        ref = coo_matrix((vals_l, (rows_l, cols_l)), shape=(d1 * d2, col))
+        wnd = np.zeros(d1 * d2)
+        wnd[fov.flatten(order=order)] = cw.flatten(order=order)
+        ref = diags([(1 / wnd).ravel()], [0]).dot(ref).tocsr()
+        ref.sort_indices()
+        a = mine.tocsr()
+        a.sort_indices()
+        assert a.shape == ref.shape
+        np.testing.assert_array_equal(a.indptr, ref.indptr)
+        np.testing.assert_array_equal(a.indices, ref.indices)
+        np.testing.assert_array_equal(a.data, ref.data)
+
+
+# ------------------------------------------------------------------ PMDArray / npz ----------
+def _toy_pmd(order="F"):
+    rng = np.random.default_rng(1)
+    d1, d2, T, R, K = 9, 7, 15, 6, 4
+    u = scipy.sparse.random(d1 * d2, R, density=0.3, random_state=2, format="coo")
+    r = rng.standard_normal((R, K)).astype(np.float32)
+    s = np.abs(rng.standard_normal(K)).astype(np.float32)
+    v = rng.standard_normal((K, T)).astype(np.float32)
+    mean = rng.standard_normal((d1, d2)).astype(np.float32)
+    std = (1 + rng.random((d1, d2))).astype(np.float32)
+    arr = localmd_amd.PMDArray(u, r, s, v, (T, d1, d2), order, mean, std)
+    dense = (u @ (r * s) @ v).reshape((d1, d2, T), order=order) * std[:, :, None] + mean[:, :, None]
+    return arr, dense.transpose(2, 0, 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("order", ["F", "C"])
+def test_pmdarray_indexing(order):
+    arr, dense = _toy_pmd(order)
+    assert arr.shape == dense.shape and arr.ndim == 3 and arr.dtype == np.float32
+    np.testing.assert_allclose(arr[3, :, :], dense[3], atol=1e-5)
+    np.testing.assert_allclose(arr[:, 2, 5], dense[:, 2, 5], atol=1e-5)
+    np.testing.assert_allclose(arr[2:6, 1:4, 2:5], dense[2:6, 1:4, 2:5], atol=1e-5)
+    np.testing.assert_allclose(arr[[1, 4]], dense[[1, 4]], atol=1e-5)
+    np.testing.assert_allclose(arr[:, 2:4], dense[:, 2:4], atol=1e-5)  # two-key form (reference: TypeError)
+    with pytest.raises(ValueError):
+        arr[None]
+    with pytest.raises(ValueError):
+        arr[1, 2, 3, 4]
+    assert scipy.sparse.isspmatrix_csr(arr.u) and arr.u.has_sorted_indices
+    for name in ("r", "s", "v", "mean_img", "var_img", "order", "row_indices"):
+        assert hasattr(arr, name)
+
+
+def test_npz_layout_roundtrip(tmp_path):
+    arr, dense = _toy_pmd()
+    fn = str(tmp_path / "out.npz")
+    localmd_amd.save_npz(fn, arr)
+    with np.load(fn, allow_pickle=True) as data:
+        assert set(data.files) == {"fov_shape", "fov_order", "U_data", "U_indices", "U_indptr", "U_shape", "U_format", "R",
+                                   "s", "Vt", "mean_img", "noise_var_img"}
+        assert data["U_data"].dtype == np.float64 and data["U_indices"].dtype == np.int32
+        assert data["U_indptr"].dtype == np.int32 and data["R"].dtype == np.float32
+        assert data["fov_order"].item() == "F" and tuple(data["fov_shape"]) == (9, 7)
+        # the reference's own loader (README.md:48-62)
+        U = scipy.sparse.csr_matrix((data["U_data"], data["U_indices"], data["U_indptr"]), shape=data["U_shape"]).tocoo()
+        assert U.shape == arr.u.shape
+    back = localmd_amd.load_npz(fn)
+    np.testing.assert_allclose(back[:, :, :], dense, atol=1e-5)
+
+
+# ------------------------------------------------------------------ dataset boundary --------
+def test_lazy_data_loader_contract(tmp_path):
+    rng = np.random.default_rng(3)
+    mov = rng.standard_normal((12, 6, 5)).astype(np.float32)
+    ds = localmd_amd.ArrayDataset(mov)
+    assert ds.shape == (12, 6, 5) and ds.ndim == 3
+    np.testing.assert_array_equal(ds[[0, 3, 5]], mov[[0, 3, 5]])
+    np.testing.assert_array_equal(ds[np.array([1, 2])], mov[[1, 2]])
+    np.testing.assert_array_equal(ds[4], mov[4])
+    np.testing.assert_array_equal(ds[2:7], mov[2:7])
+    np.testing.assert_array_equal(ds[range(2, 8, 2)], mov[2:8:2])
+    np.testing.assert_array_equal(ds[1:4, 2], mov[1:4, 2])
+    np.testing.assert_array_equal(ds[1:4, 2:4, 1], mov[1:4, 2:4, 1])
+    with pytest.raises(IndexError):
+        ds[0:13]
+    with pytest.raises(IndexError):
+        ds["a"]
+    with pytest.raises(IndexError):
+        ds[0, 0, 0, 0]
+    assert localmd_amd.PMDDataset is localmd_amd.lazy_data_loader
+
+
+@pytest.mark.parametrize("dt", [np.uint16, np.float32, np.int16, np.uint8])
+def test_tiff_reader_roundtrip(tmp_path, dt):
+    from localmd_amd._minitiff import write_tiff, MiniTiff
+
+    rng = np.random.default_rng(4)
+    frames = (rng.random((7, 11, 13)) * 200).astype(dt)
+    fn = str(tmp_path / "m.tif")
+    write_tiff(fn, frames)
+    rd = MiniTiff(fn)
+    assert rd.shape == (7, 11, 13)
+    np.testing.assert_array_equal(rd.read([0, 6, 3]), frames[[0, 6, 3]])
+    ta = localmd_amd.TiffArray(fn)
+    assert ta.shape == (7, 11, 13)
+    out = ta[[1, 2]]
+    assert out.dtype == np.float32
+    np.testing.assert_array_equal(out, frames[[1, 2]].astype(np.float32))
+    np.testing.assert_array_equal(ta[2:5], frames[2:5].astype(np.float32))
+
+
+# ------------------------------------------------------------------ C ABI surface -----------
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(_lib.LIB_PATH), "libpmd_hip.so missing: run localmd_amd/csrc/build.sh"
+    header = open(os.path.join(ROOT, "include", "pmd_hip.h")).read()
+    declared = set(re.findall(r"\b(pmdk?_[a-z0-9_]+)\s*\(", header))
+    declared.discard("pmd_ctx")
+    assert len(declared) >= 35
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    loaded = _lib.load()
+    assert loaded.pmd_version() == 1
+    # host-only helpers can be called without a device
+    assert loaded.pmd_tile_dpad(400) == 400 and loaded.pmd_tile_dpad(100) == 256 and loaded.pmd_tile_dpad(1024) == 1024
+    assert loaded.pmd_tile_dpad(1600) == 2048 and loaded.pmd_tile_dpad(3000) == -1
+    assert loaded.pmd_time_ld(10000) == 10048 + 64 and loaded.pmd_time_ld(64) == 128
+    assert loaded.pmd_tiles_workspace_bytes(2601, 20, 20, 100, 50, 10, 10000, 10112) > 0
+
+
+def test_product_fails_loudly_without_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a HIP device is present")
+    with pytest.raises(_lib.PMDLibraryError):
+        _lib.Context(0)
+    mov = np.zeros((300, 20, 20), dtype=np.float32)
+    with pytest.raises(_lib.PMDLibraryError):
+        localmd_amd.localmd_decomposition(mov, (20, 20), 300)
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "localmd_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "oracle" not in src.replace("the oracle", "").replace("oracle/", ""), fn
