@@ -129,6 +129,33 @@ int pmd_orthogonalize(pmd_ctx* ctx, float* G, int R, const float* M, int m, long
 size_t pmd_projected_svd_workspace_bytes(int rows_p, int n1, int n2);
 int pmd_projected_svd(pmd_ctx* ctx, const float* P, int rows_p, long ldp, const float* V, int n1, int n2, long ldv,
                       float* R_out, long ldr, float* s_out, float* Vt_out, long ldvt, void* ws, size_t ws_bytes);
+/* Block-sparse form of the same Gram matrix, used when R > frames (right_mat = v, decomposition.py:976-981):
+ * Gblk[pair][64][64], Gbg[tile][64][64] (tile x background), Gstrip[K][ldgs] (background rows of G).
+ * pmd_gram_apply: GM = G M without densifying G.  nbr_ptr[n_tiles+1], nbr[e] = (first M row of the
+ * block, rows in it, block index, flags: bit0 transposed, bit1 background block). */
+int pmd_gram_blocks(pmd_ctx* ctx, const float* Uw, int dpad, int b1, int b2, const int* tile_pix, const int* pairs,
+                    int n_pairs, const int* origins, const int* col_off, const int* ranks, int n_tiles, int Rt,
+                    const float* basis, long D, int K, float* Gblk, float* Gbg, float* Gstrip, long ldgs);
+int pmd_gram_apply(pmd_ctx* ctx, const float* Gblk, const float* Gbg, const float* Gstrip, long ldgs, const int* nbr_ptr,
+                   const int* nbr, const int* col_off, const int* ranks, int n_tiles, int Rt, int K, int max_rank,
+                   const float* M, long ldm, int ncols, float* GM, long ldgm);
+/* A15/A16/A17 with P = M E^T kept factored (R > frames): Et rows = eigenvectors of M^T G M / sqrt(lambda)
+ * (lambda > 0, |lambda| descending); then V = Et (M^T Z), its SVD, and R_out = M (Et^T W). */
+size_t pmd_orthogonalize_factored_workspace_bytes(int m);
+int pmd_orthogonalize_factored(pmd_ctx* ctx, const float* M, int Rc, int m, long ldm, const float* GM, long ldgm,
+                               float* Et_out, long lde, int* rprime_host, void* ws, size_t ws_bytes);
+size_t pmd_projected_svd_factored_workspace_bytes(int m, int rp, int T);
+int pmd_projected_svd_factored(pmd_ctx* ctx, const float* M, int Rc, int m, long ldm, const float* Et, int rp, long lde,
+                               const float* Z, int T, long ldz, float* R_out, long ldr, float* s_out, float* Vt_out,
+                               long ldvt, float* Vp_out, long ldvp, void* ws, size_t ws_bytes);
+/* A13/A14: CSR arrays of the sparse spatial matrix built on the device (decomposition.py:812-853, :929-930);
+ * cover1[d1][4] / cover2[d2][4]: indices of the tile-row / tile-column origins covering each FOV row / column. */
+int pmd_csr_count(pmd_ctx* ctx, int d1, int d2, int order_f, const int* cover1, const int* cover2, int n2,
+                  const int* ranks, int K, long* row_nnz);
+int pmd_csr_fill(pmd_ctx* ctx, int d1, int d2, int order_f, int b1, const int* cover1, const int* cover2,
+                 const int* orig1, const int* orig2, int n2, const int* ranks, const int* col_off, const float* Ut,
+                 int dpad, const float* w, const double* inv_cumw, const float* basis, int K, int Rt, const long* indptr,
+                 double* data, int* indices, int* zero_count);
 /* row-major C = alpha op(A) op(B) + beta C (the jnp.matmul calls of decomposition.py:873, :982, :993,
  * :1006; pmd_loader.py:412) */
 int pmd_gemm(pmd_ctx* ctx, int transA, int transB, int m, int n, int k, float alpha, const float* A, long lda,

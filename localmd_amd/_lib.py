@@ -49,6 +49,16 @@ SIGNATURES = {
     "pmd_orthogonalize": (c_i, [c_p, c_p, c_i, c_p, c_i, c_l, c_p, c_l, C.POINTER(c_i), c_p, c_sz]),
     "pmd_projected_svd_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
     "pmd_projected_svd": (c_i, [c_p, c_p, c_i, c_l, c_p, c_i, c_i, c_l, c_p, c_l, c_p, c_p, c_l, c_p, c_sz]),
+    "pmd_gram_blocks": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_p, c_l, c_i, c_p, c_p, c_p, c_l]),
+    "pmd_gram_apply": (c_i, [c_p, c_p, c_p, c_p, c_l, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_l, c_i, c_p, c_l]),
+    "pmd_orthogonalize_factored_workspace_bytes": (c_sz, [c_i]),
+    "pmd_orthogonalize_factored": (c_i, [c_p, c_p, c_i, c_i, c_l, c_p, c_l, c_p, c_l, C.POINTER(c_i), c_p, c_sz]),
+    "pmd_projected_svd_factored_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
+    "pmd_projected_svd_factored": (c_i, [c_p, c_p, c_i, c_i, c_l, c_p, c_i, c_l, c_p, c_i, c_l, c_p, c_l, c_p, c_p, c_l,
+                                         c_p, c_l, c_p, c_sz]),
+    "pmd_csr_count": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_p]),
+    "pmd_csr_fill": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_i,
+                           c_p, c_p, c_p, c_p]),
     "pmd_gemm": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_l, c_p, c_l, c_f, c_p, c_l]),
     "pmdk_tile_atx": (c_i, [c_p, c_p, c_l, c_p, c_i, c_l, c_i, c_p, c_l, c_i, c_p, c_l, c_l, c_i, c_i, c_i]),
     "pmdk_tile_xbt": (c_i, [c_p, c_p, c_l, c_p, c_i, c_l, c_i, c_p, c_l, c_l, c_p, c_l, c_l, c_i, c_i, c_i, c_i]),
@@ -73,6 +83,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: device pointers are shared with torch, so both must bind the same HIP runtime
+    # instance (torch bundles its own libamdhip64 / librocblas; whichever loads first wins).
+    import torch  # noqa: F401
+
     if not os.path.exists(LIB_PATH):
         raise PMDLibraryError(
             f"{LIB_PATH} not found: build it with localmd_amd/csrc/build.sh (there is no CPU fallback)")

@@ -215,6 +215,50 @@ int pmd_gemm(pmd_ctx* ctx, int transA, int transB, int m, int n, int k, float al
   return pmd_gemm_rm(ctx, transA, transB, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc);
 }
 
+int pmd_gram_blocks(pmd_ctx* ctx, const float* Uw, int dpad, int b1, int b2, const int* tile_pix, const int* pairs,
+                    int n_pairs, const int* origins, const int* col_off, const int* ranks, int n_tiles, int Rt,
+                    const float* basis, long D, int K, float* Gblk, float* Gbg, float* Gstrip, long ldgs) {
+  CTX_CHECK(ctx);
+  return pmd_gram_blocks_impl(ctx, Uw, dpad, b1, b2, tile_pix, pairs, n_pairs, origins, col_off, ranks, n_tiles, Rt, basis,
+                              D, K, Gblk, Gbg, Gstrip, ldgs);
+}
+int pmd_gram_apply(pmd_ctx* ctx, const float* Gblk, const float* Gbg, const float* Gstrip, long ldgs, const int* nbr_ptr,
+                   const int* nbr, const int* col_off, const int* ranks, int n_tiles, int Rt, int K, int max_rank,
+                   const float* M, long ldm, int ncols, float* GM, long ldgm) {
+  CTX_CHECK(ctx);
+  return pmd_gram_apply_impl(ctx, Gblk, Gbg, Gstrip, ldgs, nbr_ptr, nbr, col_off, ranks, n_tiles, Rt, K, max_rank, M, ldm,
+                             ncols, GM, ldgm);
+}
+int pmd_csr_count(pmd_ctx* ctx, int d1, int d2, int order_f, const int* cover1, const int* cover2, int n2,
+                  const int* ranks, int K, long* row_nnz) {
+  CTX_CHECK(ctx);
+  return pmd_csr_count_impl(ctx, d1, d2, order_f, cover1, cover2, n2, ranks, K, row_nnz);
+}
+int pmd_csr_fill(pmd_ctx* ctx, int d1, int d2, int order_f, int b1, const int* cover1, const int* cover2,
+                 const int* orig1, const int* orig2, int n2, const int* ranks, const int* col_off, const float* Ut,
+                 int dpad, const float* w, const double* inv_cumw, const float* basis, int K, int Rt, const long* indptr,
+                 double* data, int* indices, int* zero_count) {
+  CTX_CHECK(ctx);
+  return pmd_csr_fill_impl(ctx, d1, d2, order_f, b1, cover1, cover2, orig1, orig2, n2, ranks, col_off, Ut, dpad, w,
+                           inv_cumw, basis, K, Rt, indptr, data, indices, zero_count);
+}
+size_t pmd_orthogonalize_factored_workspace_bytes(int m) { return pmd_orthogonalize_factored_workspace_bytes_impl(m); }
+int pmd_orthogonalize_factored(pmd_ctx* ctx, const float* M, int Rc, int m, long ldm, const float* GM, long ldgm,
+                               float* Et_out, long lde, int* rprime_host, void* ws, size_t ws_bytes) {
+  CTX_CHECK(ctx);
+  return pmd_orthogonalize_factored_impl(ctx, M, Rc, m, ldm, GM, ldgm, Et_out, lde, rprime_host, ws, ws_bytes);
+}
+size_t pmd_projected_svd_factored_workspace_bytes(int m, int rp, int T) {
+  return pmd_projected_svd_factored_workspace_bytes_impl(m, rp, T);
+}
+int pmd_projected_svd_factored(pmd_ctx* ctx, const float* M, int Rc, int m, long ldm, const float* Et, int rp, long lde,
+                               const float* Z, int T, long ldz, float* R_out, long ldr, float* s_out, float* Vt_out,
+                               long ldvt, float* Vp_out, long ldvp, void* ws, size_t ws_bytes) {
+  CTX_CHECK(ctx);
+  return pmd_projected_svd_factored_impl(ctx, M, Rc, m, ldm, Et, rp, lde, Z, T, ldz, R_out, ldr, s_out, Vt_out, ldvt,
+                                         Vp_out, ldvp, ws, ws_bytes);
+}
+
 // ---- kernel-level entry points ---------------------------------------------------------------
 int pmdk_tile_atx(pmd_ctx* ctx, const float* X, long ldx, const int* pix, int pix_stride, long row0_stride, int d,
                   const float* A, long a_tile_stride, int a_ld, float* Out, long out_tile_stride, long ldo, int n_tiles,

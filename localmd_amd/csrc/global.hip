@@ -389,7 +389,8 @@ int pmd_projected_svd_impl(pmd_ctx* ctx, const float* P, int rows_p, long ldp, c
     RUN(pmd_gemm_rm(ctx, 0, 0, nk, n2, n1, 1.f, Wt, nk, V, ldv, 0.f, Vt_out, ldvt));
     hipLaunchKernelGGL(scale_rows2_kernel, dim3(8, nk), dim3(256), 0, ctx->stream, Vt_out, ldvt, n2, inv);
     PMD_LAUNCH_CHECK(ctx, "scale_rows2_kernel");
-    RUN(pmd_gemm_rm(ctx, 0, 1, rows_p, nk, n1, 1.f, P, ldp, Wt, nk, 0.f, R_out, ldr));
+    if (P) RUN(pmd_gemm_rm(ctx, 0, 1, rows_p, nk, n1, 1.f, P, ldp, Wt, nk, 0.f, R_out, ldr));
+    else RUN(launch_transpose(ctx, Wt, nk, nk, n1, R_out, ldr));  // no projection: R_out = W (n1 x nk)
   } else {
     // right_t = W; left = V (W / s); R = P left; Vt = W^T
     RUN(pmd_gemm_rm(ctx, 0, 1, n1, nk, n2, 1.f, V, ldv, Wt, nk, 0.f, left, nk));
@@ -435,5 +436,373 @@ int pmd_bg_project_impl(pmd_ctx* ctx, const float* xs, long D, int T, long ld, c
   // sum the block partials row by row into out[k][0:T]
   for (int k = 0; k < K; ++k)
     RUN(pmd_launch_reduce_slices(ctx, part + (long)k * ldt, 0, 64L * ldt, nblk, T, out + (long)k * ldo, 0, 1));
+  return PMD_OK;
+}
+
+// =============================================================================================
+// Block-sparse form of G = U^T U (used when the right matrix is not the identity, i.e. R > frames:
+// decomposition.py:976-981).  G is never densified: tile pairs give 64x64 blocks, the background
+// columns give one 64x64 block per tile plus a dense K x Rc strip.
+// =============================================================================================
+
+// Gblk[p][c][c'] = sum over the overlap of pair p of Uw[a][c][.] * Uw[b][c'][.]   (a <= b)
+__global__ __launch_bounds__(256) void gram_pair_blocks_kernel(const float* __restrict__ Uw, int dpad, int b1,
+                                                               const int* __restrict__ pairs,
+                                                               const int* __restrict__ origins,
+                                                               const int* __restrict__ ranks,
+                                                               float* __restrict__ Gblk) {
+  __shared__ float ua[64][65];
+  __shared__ float ub[64][65];
+  const int* pr = pairs + (long)blockIdx.x * 6;
+  const int ta = pr[0], tb = pr[1], i0 = pr[2], i1 = pr[3], j0 = pr[4], j1 = pr[5];
+  const int ra = ranks[ta], rb = ranks[tb];
+  const int ka = origins[2 * ta], ja = origins[2 * ta + 1], kb = origins[2 * tb], jb = origins[2 * tb + 1];
+  const int h = i1 - i0, npix = h * (j1 - j0);
+  const int ti = threadIdx.x >> 4, tj = threadIdx.x & 15;
+  double acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+  const float* pa = Uw + (long)ta * 64 * dpad;
+  const float* pb = Uw + (long)tb * 64 * dpad;
+  if (ra > 0 && rb > 0) {
+    for (int p0 = 0; p0 < npix; p0 += 64) {
+      for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int c = i >> 6, pl = i & 63;
+        const int p = p0 + pl;
+        float va = 0.f, vb = 0.f;
+        if (p < npix) {
+          const int jj = p / h, ii = p - jj * h;
+          const int gi = i0 + ii, gj = j0 + jj;
+          if (c < ra) va = pa[(long)c * dpad + (gi - ka) + b1 * (gj - ja)];
+          if (c < rb) vb = pb[(long)c * dpad + (gi - kb) + b1 * (gj - jb)];
+        }
+        ua[c][pl] = va;
+        ub[c][pl] = vb;
+      }
+      __syncthreads();
+#pragma unroll 4
+      for (int pl = 0; pl < 64; ++pl) {
+        double av[4], bv[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) { av[a] = (double)ua[4 * ti + a][pl]; bv[a] = (double)ub[4 * tj + a][pl]; }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) acc[a][b] = fma(av[a], bv[b], acc[a][b]);
+      }
+      __syncthreads();
+    }
+  }
+  float* g = Gblk + (long)blockIdx.x * 4096;
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) g[(4 * ti + a) * 64 + 4 * tj + b] = (float)acc[a][b];
+}
+
+// Gbg[tile][c][k] = sum_q Uw[tile][c][q] * basis[pix[q]][k]; also scattered into the dense strip
+// Gstrip[k][off + c] (K x ldgs).
+__global__ __launch_bounds__(256) void gram_bg_blocks_kernel(const float* __restrict__ Uw, int dpad, int d,
+                                                             const int* __restrict__ pix,
+                                                             const float* __restrict__ basis, int K,
+                                                             const int* __restrict__ col_off,
+                                                             const int* __restrict__ ranks, float* __restrict__ Gbg,
+                                                             float* __restrict__ Gstrip, long ldgs) {
+  const int tile = blockIdx.x;
+  const int rk = ranks[tile];
+  const long off = col_off[tile];
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int c = i >> 6, k = i & 63;
+    float v = 0.f;
+    if (c < rk && k < K) {
+      double s = 0.0;
+      for (int q = 0; q < d; ++q)
+        s += (double)Uw[(long)tile * 64 * dpad + (long)c * dpad + q] * (double)basis[(long)pix[(long)tile * d + q] * K + k];
+      v = (float)s;
+      Gstrip[(long)k * ldgs + off + c] = v;
+    }
+    Gbg[(long)tile * 4096 + i] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void gram_bgbg_strip_kernel(const float* __restrict__ basis, long D, int K, int Rt,
+                                                              float* __restrict__ Gstrip, long ldgs) {
+  __shared__ double red[256];
+  const int k1 = blockIdx.x, k2 = blockIdx.y;
+  if (k2 < k1) return;
+  double s = 0.0;
+  for (long c = threadIdx.x; c < D; c += 256) s += (double)basis[c * K + k1] * (double)basis[c * K + k2];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    Gstrip[(long)k1 * ldgs + Rt + k2] = (float)red[0];
+    Gstrip[(long)k2 * ldgs + Rt + k1] = (float)red[0];
+  }
+}
+
+// GM[off_a + c][x] = sum over neighbour blocks (b, c') of G_ab[c][c'] * M[off_b + c'][x]
+// nbr_ptr[a] .. nbr_ptr[a+1]: entries (row offset of the block's M rows, rows in the block,
+// block index into Gblk/Gbg, flags: bit0 = use the transposed block, bit1 = background block).
+template <int NOUT>
+__global__ __launch_bounds__(256) void gram_apply_kernel(const float* __restrict__ Gblk, const float* __restrict__ Gbg,
+                                                         const int* __restrict__ nbr_ptr, const int* __restrict__ nbr,
+                                                         const int* __restrict__ col_off, const int* __restrict__ ranks,
+                                                         const float* __restrict__ M, long ldm, int ncols,
+                                                         float* __restrict__ GM, long ldgm) {
+  __shared__ float g[64][NOUT + 1];  // g[c'][c]
+  const int a = blockIdx.y;
+  const int ra = ranks[a];
+  if (ra == 0) return;
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  double acc[NOUT];
+#pragma unroll
+  for (int c = 0; c < NOUT; ++c) acc[c] = 0.0;
+  for (int e = nbr_ptr[a]; e < nbr_ptr[a + 1]; ++e) {
+    const int row0 = nbr[4 * e], rb = nbr[4 * e + 1], blk = nbr[4 * e + 2], flags = nbr[4 * e + 3];
+    const float* src = (flags & 2) ? Gbg + (long)blk * 4096 : Gblk + (long)blk * 4096;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * NOUT; i += 256) {
+      const int cp = i / NOUT, c = i - cp * NOUT;
+      // stored block is [row-tile comp][col-tile comp]; transposed flag: this tile is the column tile
+      g[cp][c] = (flags & 1) ? src[cp * 64 + c] : src[c * 64 + cp];
+    }
+    __syncthreads();
+    if (x < ncols) {
+      for (int cp = 0; cp < rb; ++cp) {
+        const double v = (double)M[(long)(row0 + cp) * ldm + x];
+#pragma unroll
+        for (int c = 0; c < NOUT; ++c) acc[c] = fma((double)g[cp][c], v, acc[c]);
+      }
+    }
+  }
+  if (x < ncols) {
+    const long off = col_off[a];
+#pragma unroll
+    for (int c = 0; c < NOUT; ++c)
+      if (c < ra) GM[(off + c) * ldgm + x] = (float)acc[c];
+  }
+}
+
+// blocks: Gblk [n_pairs][64][64], Gbg [n_tiles][64][64], Gstrip [K][ldgs] (ldgs >= Rt + K)
+int pmd_gram_blocks_impl(pmd_ctx* ctx, const float* Uw, int dpad, int b1, int b2, const int* pix, const int* pairs,
+                         int n_pairs, const int* origins, const int* col_off, const int* ranks, int n_tiles, int Rt,
+                         const float* basis, long D, int K, float* Gblk, float* Gbg, float* Gstrip, long ldgs) {
+  pmd_prof_scope prof__(ctx, "gram_blocks");
+  if (n_pairs > 0) {
+    hipLaunchKernelGGL(gram_pair_blocks_kernel, dim3(n_pairs), dim3(256), 0, ctx->stream, Uw, dpad, b1, pairs, origins,
+                       ranks, Gblk);
+    PMD_LAUNCH_CHECK(ctx, "gram_pair_blocks_kernel");
+  }
+  if (K > 0) {
+    PMD_HIP(ctx, hipMemsetAsync(Gstrip, 0, (size_t)K * ldgs * sizeof(float), ctx->stream));
+    hipLaunchKernelGGL(gram_bg_blocks_kernel, dim3(n_tiles), dim3(256), 0, ctx->stream, Uw, dpad, b1 * b2, pix, basis, K,
+                       col_off, ranks, Gbg, Gstrip, ldgs);
+    PMD_LAUNCH_CHECK(ctx, "gram_bg_blocks_kernel");
+    hipLaunchKernelGGL(gram_bgbg_strip_kernel, dim3(K, K), dim3(256), 0, ctx->stream, basis, D, K, Rt, Gstrip, ldgs);
+    PMD_LAUNCH_CHECK(ctx, "gram_bgbg_strip_kernel");
+  }
+  return PMD_OK;
+}
+
+// GM = G M for the block-sparse G (rows of the K background columns via one small GEMM).
+int pmd_gram_apply_impl(pmd_ctx* ctx, const float* Gblk, const float* Gbg, const float* Gstrip, long ldgs,
+                        const int* nbr_ptr, const int* nbr, const int* col_off, const int* ranks, int n_tiles, int Rt,
+                        int K, int max_rank, const float* M, long ldm, int ncols, float* GM, long ldgm) {
+  {
+    pmd_prof_scope prof__(ctx, "gram_apply");
+    dim3 grid((ncols + 255) / 256, n_tiles);
+    if (max_rank <= 16)
+      hipLaunchKernelGGL(gram_apply_kernel<16>, grid, dim3(256), 0, ctx->stream, Gblk, Gbg, nbr_ptr, nbr, col_off, ranks,
+                         M, ldm, ncols, GM, ldgm);
+    else if (max_rank <= 32)
+      hipLaunchKernelGGL(gram_apply_kernel<32>, grid, dim3(256), 0, ctx->stream, Gblk, Gbg, nbr_ptr, nbr, col_off, ranks,
+                         M, ldm, ncols, GM, ldgm);
+    else
+      hipLaunchKernelGGL(gram_apply_kernel<64>, grid, dim3(256), 0, ctx->stream, Gblk, Gbg, nbr_ptr, nbr, col_off, ranks,
+                         M, ldm, ncols, GM, ldgm);
+    PMD_LAUNCH_CHECK(ctx, "gram_apply_kernel");
+  }
+  if (K > 0) RUN(pmd_gemm_rm(ctx, 0, 0, K, ncols, Rt + K, 1.f, Gstrip, ldgs, M, ldm, 0.f, GM + (long)Rt * ldgm, ldgm));
+  return PMD_OK;
+}
+
+// =============================================================================================
+// CSR assembly of the sparse spatial matrix on the device (decomposition.py:812-853, :929-930):
+// row p (output pixel order) holds, for every covering tile in tile order, rank_t entries
+// (float64(U) * w) * (1/cumw), then the K background entries.  cover1[i][0..3] / cover2[j][0..3]
+// list the indices of the tile-row / tile-column origins covering FOV row i / column j (-1 pads).
+// =============================================================================================
+__device__ __forceinline__ void csr_pixel(long p, int d1, int d2, int order_f, int* i, int* j) {
+  if (order_f) { *j = (int)(p / d1); *i = (int)(p - (long)(*j) * d1); }
+  else { *i = (int)(p / d2); *j = (int)(p - (long)(*i) * d2); }
+}
+
+__global__ void csr_count_kernel(int d1, int d2, int order_f, const int* __restrict__ cover1,
+                                 const int* __restrict__ cover2, int n2, const int* __restrict__ ranks, int K,
+                                 long* __restrict__ row_nnz) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= (long)d1 * d2) return;
+  int i, j;
+  csr_pixel(p, d1, d2, order_f, &i, &j);
+  long n = K;
+  for (int a = 0; a < 4; ++a) {
+    const int ki = cover1[4 * i + a];
+    if (ki < 0) continue;
+    for (int b = 0; b < 4; ++b) {
+      const int ji = cover2[4 * j + b];
+      if (ji >= 0) n += ranks[ki * n2 + ji];
+    }
+  }
+  row_nnz[p] = n;
+}
+
+__global__ void csr_fill_kernel(int d1, int d2, int order_f, int b1, const int* __restrict__ cover1,
+                                const int* __restrict__ cover2, const int* __restrict__ orig1,
+                                const int* __restrict__ orig2, int n2, const int* __restrict__ ranks,
+                                const int* __restrict__ col_off, const float* __restrict__ Ut, int dpad,
+                                const float* __restrict__ w, const double* __restrict__ inv_cumw,
+                                const float* __restrict__ basis, int K, int Rt, const long* __restrict__ indptr,
+                                double* __restrict__ data, int* __restrict__ indices, int* __restrict__ zero_count) {
+  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= (long)d1 * d2) return;
+  int i, j;
+  csr_pixel(p, d1, d2, order_f, &i, &j);
+  long pos = indptr[p];
+  const double inv = inv_cumw[(long)i * d2 + j];
+  int zeros = 0;
+  for (int a = 0; a < 4; ++a) {
+    const int ki = cover1[4 * i + a];
+    if (ki < 0) continue;
+    for (int b = 0; b < 4; ++b) {
+      const int ji = cover2[4 * j + b];
+      if (ji < 0) continue;
+      const int tile = ki * n2 + ji;
+      const int q = (i - orig1[ki]) + b1 * (j - orig2[ji]);
+      const double wq = (double)w[q];
+      const int rk = ranks[tile];
+      const int off = col_off[tile];
+      for (int c = 0; c < rk; ++c) {
+        const double v = ((double)Ut[(long)tile * 64 * dpad + (long)c * dpad + q] * wq) * inv;
+        zeros += (v == 0.0);
+        data[pos] = v;
+        indices[pos] = off + c;
+        ++pos;
+      }
+    }
+  }
+  for (int k = 0; k < K; ++k) {
+    const double v = (double)basis[((long)i * d2 + j) * K + k];
+    zeros += (v == 0.0);
+    data[pos] = v;
+    indices[pos] = Rt + k;
+    ++pos;
+  }
+  if (zeros) atomicAdd(zero_count, zeros);
+}
+
+int pmd_csr_count_impl(pmd_ctx* ctx, int d1, int d2, int order_f, const int* cover1, const int* cover2, int n2,
+                       const int* ranks, int K, long* row_nnz) {
+  pmd_prof_scope prof__(ctx, "csr_assembly");
+  const long D = (long)d1 * d2;
+  hipLaunchKernelGGL(csr_count_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, ctx->stream, d1, d2, order_f,
+                     cover1, cover2, n2, ranks, K, row_nnz);
+  PMD_LAUNCH_CHECK(ctx, "csr_count_kernel");
+  return PMD_OK;
+}
+
+int pmd_csr_fill_impl(pmd_ctx* ctx, int d1, int d2, int order_f, int b1, const int* cover1, const int* cover2,
+                      const int* orig1, const int* orig2, int n2, const int* ranks, const int* col_off, const float* Ut,
+                      int dpad, const float* w, const double* inv_cumw, const float* basis, int K, int Rt,
+                      const long* indptr, double* data, int* indices, int* zero_count) {
+  pmd_prof_scope prof__(ctx, "csr_assembly");
+  const long D = (long)d1 * d2;
+  PMD_HIP(ctx, hipMemsetAsync(zero_count, 0, sizeof(int), ctx->stream));
+  hipLaunchKernelGGL(csr_fill_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, ctx->stream, d1, d2, order_f, b1,
+                     cover1, cover2, orig1, orig2, n2, ranks, col_off, Ut, dpad, w, inv_cumw, basis, K, Rt, indptr, data,
+                     indices, zero_count);
+  PMD_LAUNCH_CHECK(ctx, "csr_fill_kernel");
+  return PMD_OK;
+}
+
+// =============================================================================================
+// Factored form of A15 + A16 + A17 for R > frames (P = M E^T is never formed):
+//   pmd_orthogonalize_factored: C = M^T (G M) -> Et (R' x m), rows = eigenvectors / sqrt(lambda)
+//   pmd_projected_svd_factored: V = Et (M^T Z); SVD of V; R_out = M (Et^T W)
+// =============================================================================================
+size_t pmd_orthogonalize_factored_workspace_bytes_impl(int m) {
+  return (size_t)m * m * sizeof(float) + (size_t)m * (3 * sizeof(float) + sizeof(int)) + 8192;
+}
+
+int pmd_orthogonalize_factored_impl(pmd_ctx* ctx, const float* M, int Rc, int m, long ldm, const float* GM, long ldgm,
+                                    float* Et_out, long lde, int* rprime_out, void* ws, size_t ws_bytes) {
+  pmd_arena ar(ws, ws_bytes);
+  float* C = ar.take_n<float>((size_t)m * m);
+  float* w = ar.take_n<float>(m);
+  float* work = ar.take_n<float>(m);
+  float* scale = ar.take_n<float>(m);
+  int* perm = ar.take_n<int>(m);
+  int* info = ar.take_n<int>(4);
+  if (ar.overflow) return pmd_fail(ctx, PMD_ERR_WORKSPACE, "pmd_orthogonalize_factored", "workspace too small");
+  RUN(pmd_gemm_rm(ctx, 1, 0, m, m, Rc, 1.f, M, ldm, GM, ldgm, 0.f, C, m));
+  RUN(pmd_syevd(ctx, m, C, m, w, work, info));
+  std::vector<float> hw(m);
+  int hinfo = 0;
+  PMD_HIP(ctx, hipMemcpyAsync(hw.data(), w, (size_t)m * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  PMD_HIP(ctx, hipMemcpyAsync(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  PMD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (hinfo != 0) return pmd_fail(ctx, PMD_ERR_BLAS, "rocsolver_ssyevd", "did not converge");
+  std::vector<int> idx(m);
+  for (int i = 0; i < m; ++i) idx[i] = i;
+  std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return std::fabs(hw[a]) > std::fabs(hw[b]); });
+  std::vector<int> hperm;
+  std::vector<float> hscale;
+  for (int i = 0; i < m; ++i)
+    if (hw[idx[i]] > 0.f) {
+      hperm.push_back(idx[i]);
+      hscale.push_back(1.0f / std::sqrt(hw[idx[i]]));
+    }
+  const int rp = (int)hperm.size();
+  *rprime_out = rp;
+  if (rp == 0) return PMD_OK;
+  PMD_HIP(ctx, hipMemcpyAsync(perm, hperm.data(), (size_t)rp * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  PMD_HIP(ctx, hipMemcpyAsync(scale, hscale.data(), (size_t)rp * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  RUN(launch_gather_rows(ctx, C, m, perm, scale, rp, m, Et_out, lde));
+  PMD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return PMD_OK;
+}
+
+size_t pmd_projected_svd_factored_workspace_bytes_impl(int m, int rp, int T) {
+  return (size_t)m * T * sizeof(float) + (size_t)rp * T * sizeof(float) + (size_t)m * rp * sizeof(float) +
+         pmd_projected_svd_workspace_bytes_impl(1, rp, T) + 16384;
+}
+
+// M: Rc x m; Et: rp x m; Z: Rc x T.  Outputs R_out (Rc x nk), s (nk), Vt (nk x T), nk = min(rp, T);
+// Vp_out (rp x T, optional, may be NULL) receives V = P^T Z.
+int pmd_projected_svd_factored_impl(pmd_ctx* ctx, const float* M, int Rc, int m, long ldm, const float* Et, int rp,
+                                    long lde, const float* Z, int T, long ldz, float* R_out, long ldr, float* s_out,
+                                    float* Vt_out, long ldvt, float* Vp_out, long ldvp, void* ws, size_t ws_bytes) {
+  if (rp > T) return pmd_fail(ctx, PMD_ERR_UNSUPPORTED, "pmd_projected_svd_factored", "needs R' <= T");
+  pmd_arena ar(ws, ws_bytes);
+  float* W1 = ar.take_n<float>((size_t)m * T);
+  float* Vp = Vp_out ? Vp_out : ar.take_n<float>((size_t)rp * T);
+  const long ldv = Vp_out ? ldvp : T;
+  float* X1 = ar.take_n<float>((size_t)m * rp);
+  const size_t sub_bytes = pmd_projected_svd_workspace_bytes_impl(1, rp, T);
+  void* sub = ar.take(sub_bytes);
+  if (ar.overflow) return pmd_fail(ctx, PMD_ERR_WORKSPACE, "pmd_projected_svd_factored", "workspace too small");
+  RUN(pmd_gemm_rm(ctx, 1, 0, m, T, Rc, 1.f, M, ldm, Z, ldz, 0.f, W1, T));      // M^T Z
+  RUN(pmd_gemm_rm(ctx, 0, 0, rp, T, m, 1.f, Et, lde, W1, T, 0.f, Vp, ldv));     // V = Et (M^T Z)
+  // SVD of V with the identity as projection: the "R" it returns is W (rp x rp), reuse W1's memory
+  float* Wmat = W1;  // rp x rp  (rp <= m, T)
+  RUN(pmd_projected_svd_impl(ctx, nullptr, 0, 0, Vp, rp, T, ldv, Wmat, rp, s_out, Vt_out, ldvt, sub, sub_bytes));
+  // R = M (Et^T W)
+  RUN(pmd_gemm_rm(ctx, 1, 0, m, rp, rp, 1.f, Et, lde, Wmat, rp, 0.f, X1, rp));
+  RUN(pmd_gemm_rm(ctx, 0, 0, Rc, rp, m, 1.f, M, ldm, X1, rp, 0.f, R_out, ldr));
   return PMD_OK;
 }

@@ -87,3 +87,24 @@ int pmd_projected_svd_impl(pmd_ctx* ctx, const float* P, int rows_p, long ldp, c
 size_t pmd_bg_project_workspace_bytes_impl(long D, int T);
 int pmd_bg_project_impl(pmd_ctx* ctx, const float* xs, long D, int T, long ld, const float* basis, int K, float* out,
                         long ldo, void* ws, size_t ws_bytes);
+
+// global.hip: block-sparse Gram, device CSR assembly, factored orthogonalisation / SVD
+int pmd_gram_blocks_impl(pmd_ctx* ctx, const float* Uw, int dpad, int b1, int b2, const int* pix, const int* pairs,
+                         int n_pairs, const int* origins, const int* col_off, const int* ranks, int n_tiles, int Rt,
+                         const float* basis, long D, int K, float* Gblk, float* Gbg, float* Gstrip, long ldgs);
+int pmd_gram_apply_impl(pmd_ctx* ctx, const float* Gblk, const float* Gbg, const float* Gstrip, long ldgs,
+                        const int* nbr_ptr, const int* nbr, const int* col_off, const int* ranks, int n_tiles, int Rt,
+                        int K, int max_rank, const float* M, long ldm, int ncols, float* GM, long ldgm);
+int pmd_csr_count_impl(pmd_ctx* ctx, int d1, int d2, int order_f, const int* cover1, const int* cover2, int n2,
+                       const int* ranks, int K, long* row_nnz);
+int pmd_csr_fill_impl(pmd_ctx* ctx, int d1, int d2, int order_f, int b1, const int* cover1, const int* cover2,
+                      const int* orig1, const int* orig2, int n2, const int* ranks, const int* col_off, const float* Ut,
+                      int dpad, const float* w, const double* inv_cumw, const float* basis, int K, int Rt,
+                      const long* indptr, double* data, int* indices, int* zero_count);
+size_t pmd_orthogonalize_factored_workspace_bytes_impl(int m);
+int pmd_orthogonalize_factored_impl(pmd_ctx* ctx, const float* M, int Rc, int m, long ldm, const float* GM, long ldgm,
+                                    float* Et_out, long lde, int* rprime_out, void* ws, size_t ws_bytes);
+size_t pmd_projected_svd_factored_workspace_bytes_impl(int m, int rp, int T);
+int pmd_projected_svd_factored_impl(pmd_ctx* ctx, const float* M, int Rc, int m, long ldm, const float* Et, int rp,
+                                    long lde, const float* Z, int T, long ldz, float* R_out, long ldr, float* s_out,
+                                    float* Vt_out, long ldvt, float* Vp_out, long ldvp, void* ws, size_t ws_bytes);

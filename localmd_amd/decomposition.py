@@ -103,6 +103,16 @@ class _Movie:
         return out, ld
 
 
+def _to_host(t):
+    """Device tensor -> NumPy through page-locked memory (PCIe rate instead of pageable-copy rate).
+    The array owns its pinned block until it is garbage collected."""
+    torch = _torch()
+    out = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    out.copy_(t, non_blocking=True)
+    torch.cuda.current_stream().synchronize()
+    return out.numpy()
+
+
 def _sparse_u(ut_host, ranks, pix_f, block_weights, inv_cumw_rows, n_rows):
     """Sparse assembly of decomposition.py:812-853 (COO triplets, weights, row normalisation),
     vectorised.  ut_host: (n_tiles, 64, dpad) float32; pix_f: (n_tiles, d) row ids of the output
@@ -405,46 +415,66 @@ def localmd_decomposition(
         lap("tiles", t0)
         _dbg("ut", ut_dev); _dbg("v_tiles", v_dev[:, :, :crop]); _dbg("tile_lambda", lam_dev)
 
-        # ---- sparse assembly (decomposition.py:752-857) on the host: integers + float64 scaling
+        # ---- sparse assembly (decomposition.py:752-857): CSR arrays built on the device
         t0 = time.perf_counter()
         ranks = ranks_dev.cpu().numpy().astype(np.int64)
-        ut_host = ut_dev.cpu().numpy()
-        fov_ids = np.arange(D).reshape((d1, d2), order=order)
-        pix_f = fov_ids.reshape(-1)[pix_c]  # output row id of every tile pixel
-        cumw = grid.cumulative_weights((d1, d2), block_sizes, origins, block_weights)
-        inv_rows = np.zeros(D)
-        inv_rows[fov_ids.reshape(-1)] = 1.0 / cumw.reshape(-1)
-        u_local, offsets = _sparse_u(ut_host, ranks, pix_f, block_weights, inv_rows, D)
+        offsets = np.concatenate([[0], np.cumsum(ranks)]).astype(np.int64)
         Rt = int(offsets[-1])
-        if K > 0:
-            basis_host = basis_dev.cpu().numpy()  # rows in C-order pixels
-            basis_rows = np.empty_like(basis_host)
-            basis_rows[fov_ids.reshape(-1)] = basis_host
-            u_r = scipy.sparse.hstack([u_local, coo_matrix(basis_rows)])
-            K_cols = K
-        else:
-            u_r = scipy.sparse.hstack([u_local, coo_matrix((D, 1), dtype=np.float32)])
-            K_cols = 1
+        K_cols = K if K > 0 else 1  # K <= 0: one empty placeholder column (pmd_loader.py:301-302)
         R = Rt + K_cols
+        Rc = Rt + max(K, 0)         # columns with content
+        fov_ids = np.arange(D).reshape((d1, d2), order=order)
+        cumw = grid.cumulative_weights((d1, d2), block_sizes, origins, block_weights)
+        cover1, cover2 = grid.cover_tables((d1, d2), block_sizes, dim_1_iters, dim_2_iters)
+        col_off_dev = _i32(ctx, offsets[:-1])
+        w_dev = _f32(ctx, block_weights.reshape(-1, order="F"))
+        inv_cumw_dev = torch.from_numpy(np.ascontiguousarray(1.0 / cumw.reshape(-1))).to(ctx.device)
+        cov1_dev, cov2_dev = _i32(ctx, cover1), _i32(ctx, cover2)
+        o1_dev, o2_dev = _i32(ctx, dim_1_iters), _i32(ctx, dim_2_iters)
+        row_nnz = torch.empty(D, dtype=torch.int64, device=ctx.device)
+        n2 = len(dim_2_iters)
+        order_f = 1 if order == "F" else 0
+        ctx.call("pmd_csr_count", d1, d2, order_f, ptr(cov1_dev), ptr(cov2_dev), n2, ptr(ranks_dev), max(K, 0), ptr(row_nnz))
+        indptr_dev = torch.zeros(D + 1, dtype=torch.int64, device=ctx.device)
+        indptr_dev[1:] = torch.cumsum(row_nnz, 0)
+        nnz = int(indptr_dev[-1].item())
+        data_dev = torch.empty(max(nnz, 1), dtype=torch.float64, device=ctx.device)
+        idx_dev = torch.empty(max(nnz, 1), dtype=torch.int32, device=ctx.device)
+        zero_dev = torch.zeros(1, dtype=torch.int32, device=ctx.device)
+        ctx.call("pmd_csr_fill", d1, d2, order_f, b1, ptr(cov1_dev), ptr(cov2_dev), ptr(o1_dev), ptr(o2_dev), n2,
+                 ptr(ranks_dev), ptr(col_off_dev), ptr(ut_dev), dpad, ptr(w_dev), ptr(inv_cumw_dev), ptr(basis_dev),
+                 max(K, 0), Rt, ptr(indptr_dev), ptr(data_dev), ptr(idx_dev), ptr(zero_dev))
+        ut_host = None
+        basis_rows = None
+        if int(zero_dev.item()) == 0 and nnz < 2 ** 31:
+            u_r = scipy.sparse.csr_matrix(
+                (_to_host(data_dev[:nnz]), _to_host(idx_dev[:nnz]), indptr_dev.cpu().numpy().astype(np.int32)), shape=(D, R))
+        else:
+            # exact zeros present (the reference drops them, decomposition.py:853): host construction
+            ut_host = ut_dev.cpu().numpy()
+            pix_f = fov_ids.reshape(-1)[pix_c]
+            inv_rows = np.zeros(D)
+            inv_rows[fov_ids.reshape(-1)] = 1.0 / cumw.reshape(-1)
+            u_local, _ = _sparse_u(ut_host, ranks, pix_f, block_weights, inv_rows, D)
+            if K > 0:
+                basis_rows = np.empty((D, K), dtype=np.float32)
+                basis_rows[fov_ids.reshape(-1)] = basis_dev.cpu().numpy()
+                u_r = scipy.sparse.hstack([u_local, coo_matrix(basis_rows)])
+            else:
+                u_r = scipy.sparse.hstack([u_local, coo_matrix((D, 1), dtype=np.float32)])
         display("Normalizing by weights")
-        display("The total rank before pruning is {}".format(u_r.shape[1]))
+        display("The total rank before pruning is {}".format(R))
         lap("assembly", t0)
 
         # ---- orthogonalisation (decomposition.py:860-881)
         display("Performing rank pruning and orthogonalization for fast sparse regression.")
         t0 = time.perf_counter()
-        Rc = Rt + max(K, 0)  # columns with content (the K<=0 placeholder column is empty)
-        col_off_dev = _i32(ctx, offsets[:-1])
-        w_dev = _f32(ctx, block_weights.reshape(-1, order="F"))
         cumw_dev = _f32(ctx, cumw.reshape(-1))
         uw_dev = torch.empty_like(ut_dev)
         ctx.call("pmd_weight_tiles", ptr(ut_dev), dpad, ptr(pix_dev), d, ptr(w_dev), ptr(cumw_dev), ptr(ranks_dev),
                  ptr(uw_dev), n_tiles)
         pairs = grid.overlap_pairs(origins, block_sizes)
         pairs_dev, origins_dev = _i32(ctx, pairs), _i32(ctx, origins)
-        G = torch.empty((Rc, Rc), dtype=torch.float32, device=ctx.device)
-        ctx.call("pmd_gram_u", ptr(uw_dev), dpad, b1, b2, ptr(pix_dev), ptr(pairs_dev), pairs.shape[0], ptr(origins_dev),
-                 ptr(col_off_dev), ptr(ranks_dev), n_tiles, Rt, ptr(basis_dev), D, max(K, 0), ptr(G), Rc)
 
         # v_cropped = [tile traces ; background temporal basis] (decomposition.py:844, :932)
         m_cols = crop
@@ -464,12 +494,38 @@ def localmd_decomposition(
             ctx.call("pmd_gemm", 0, 0, Rc, n_rand, crop, 1.0, ptr(vc), m_cols, ptr(rand), n_rand, 0.0, ptr(right), n_rand)
             m_cols = n_rand
         use_right = R > m_cols  # decomposition.py:976 (R counts the placeholder column too)
-        _dbg("G", G); _dbg("v_cropped", vc)
-        P_dev, rp = _orthogonalize(ctx, G, Rc, right if use_right else None, m_cols, m_cols)
-        ldp = P_dev.shape[1]
+        _dbg("v_cropped", vc)
+        P_dev = Et_dev = None
+        if use_right:
+            # P = right E / sqrt(lambda) stays factored; G = U^T U stays block-sparse
+            n_pairs = pairs.shape[0]
+            gblk = torch.empty((max(n_pairs, 1), 64, 64), dtype=torch.float32, device=ctx.device)
+            gbg = torch.zeros((n_tiles, 64, 64), dtype=torch.float32, device=ctx.device)
+            gstrip = torch.zeros((max(K, 1), Rc), dtype=torch.float32, device=ctx.device)
+            ctx.call("pmd_gram_blocks", ptr(uw_dev), dpad, b1, b2, ptr(pix_dev), ptr(pairs_dev), n_pairs, ptr(origins_dev),
+                     ptr(col_off_dev), ptr(ranks_dev), n_tiles, Rt, ptr(basis_dev), D, max(K, 0), ptr(gblk), ptr(gbg),
+                     ptr(gstrip), Rc)
+            nbr_ptr, nbr = grid.neighbour_lists(pairs, ranks, offsets[:-1], n_tiles, Rt, max(K, 0))
+            nbr_ptr_dev, nbr_dev = _i32(ctx, nbr_ptr), _i32(ctx, nbr)
+            GM = torch.empty((Rc, m_cols), dtype=torch.float32, device=ctx.device)
+            ctx.call("pmd_gram_apply", ptr(gblk), ptr(gbg), ptr(gstrip), Rc, ptr(nbr_ptr_dev), ptr(nbr_dev), ptr(col_off_dev),
+                     ptr(ranks_dev), n_tiles, Rt, max(K, 0), int(ranks.max()) if n_tiles else 0, ptr(right), m_cols, m_cols,
+                     ptr(GM), m_cols)
+            Et_dev = torch.empty((m_cols, m_cols), dtype=torch.float32, device=ctx.device)
+            ws = ctx.workspace(lib.pmd_orthogonalize_factored_workspace_bytes(m_cols))
+            rp_c = c_i(0)
+            ctx.call("pmd_orthogonalize_factored", ptr(right), Rc, m_cols, m_cols, ptr(GM), m_cols, ptr(Et_dev), m_cols,
+                     C.byref(rp_c), ptr(ws), ws.numel())
+            rp = int(rp_c.value)
+            del GM, gblk, gbg
+        else:
+            G = torch.empty((Rc, Rc), dtype=torch.float32, device=ctx.device)
+            ctx.call("pmd_gram_u", ptr(uw_dev), dpad, b1, b2, ptr(pix_dev), ptr(pairs_dev), pairs.shape[0], ptr(origins_dev),
+                     ptr(col_off_dev), ptr(ranks_dev), n_tiles, Rt, ptr(basis_dev), D, max(K, 0), ptr(G), Rc)
+            _dbg("G", G)
+            P_dev, rp = _orthogonalize(ctx, G, Rc, None, m_cols, m_cols)
+            del G
         display("After performing rank reduction, the updated rank is {}".format(rp))
-        _dbg("P", P_dev[:, :rp])
-        del G
         lap("orthogonalize", t0)
 
         # ---- V = P^T U^T X over the whole movie (pmd_loader.py:316-346)
@@ -491,30 +547,48 @@ def localmd_decomposition(
                 ws = ctx.workspace(lib.pmd_bg_project_workspace_bytes(D, T))
                 ctx.call("pmd_bg_project", ptr(xs_full), D, T, ld_T, ptr(basis_dev), K, ptr(pj_full), ld_T, ptr(ws), ws.numel())
                 Z[Rt:Rt + K, :] = pj_full[:, :T]
-        Vp = torch.empty((rp, T), dtype=torch.float32, device=ctx.device)
-        ctx.call("pmd_gemm", 1, 0, rp, T, Rc, 1.0, ptr(P_dev), ldp, ptr(Z), T, 0.0, ptr(Vp), T)
-        _dbg("Z", Z); _dbg("Vp", Vp)
+        _dbg("Z", Z)
         lap("v_projection", t0)
 
-        # ---- final SVD (decomposition.py:894-904)
+        # ---- V = P^T Z and the final SVD (decomposition.py:885, :894-904)
         display("Final reformat of data into complete SVD")
         t0 = time.perf_counter()
         if rp <= T:
             display("Short matrix, using leftward SVD routine")
         else:
             display("Tall matrix, using rightward SVD routine")
-        R_out, s_out, Vt_out = _projected_svd_dev(ctx, P_dev, Rc, ldp, Vp, rp, T, T)
+        Vp = torch.empty((rp, T), dtype=torch.float32, device=ctx.device) if return_diagnostics else None
+        if use_right and rp <= T:
+            nk = rp
+            R_out = torch.empty((Rc, nk), dtype=torch.float32, device=ctx.device)
+            s_out = torch.empty((nk,), dtype=torch.float32, device=ctx.device)
+            Vt_out = torch.empty((nk, T), dtype=torch.float32, device=ctx.device)
+            ws = ctx.workspace(lib.pmd_projected_svd_factored_workspace_bytes(m_cols, rp, T))
+            ctx.call("pmd_projected_svd_factored", ptr(right), Rc, m_cols, m_cols, ptr(Et_dev), rp, m_cols, ptr(Z), T, T,
+                     ptr(R_out), nk, ptr(s_out), ptr(Vt_out), T, ptr(Vp), T, ptr(ws), ws.numel())
+        else:
+            if P_dev is None:  # factored P with R' > T (rank_prune corner): materialise P = right Et^T
+                P_dev = torch.empty((Rc, m_cols), dtype=torch.float32, device=ctx.device)
+                ctx.call("pmd_gemm", 0, 1, Rc, rp, m_cols, 1.0, ptr(right), m_cols, ptr(Et_dev), m_cols, 0.0, ptr(P_dev), m_cols)
+            ldp = P_dev.shape[1]
+            if Vp is None:
+                Vp = torch.empty((rp, T), dtype=torch.float32, device=ctx.device)
+            ctx.call("pmd_gemm", 1, 0, rp, T, Rc, 1.0, ptr(P_dev), ldp, ptr(Z), T, 0.0, ptr(Vp), T)
+            R_out, s_out, Vt_out = _projected_svd_dev(ctx, P_dev, Rc, ldp, Vp, rp, T, T)
         ctx.sync()
-        r_mat = R_out.cpu().numpy()
-        s = s_out.cpu().numpy()
-        vt = Vt_out.cpu().numpy()
+        lap("final_svd", t0)
+        t0 = time.perf_counter()
+        r_mat = _to_host(R_out)
+        s = _to_host(s_out)
+        vt = _to_host(Vt_out)
         if K_cols != max(K, 0):
             r_mat = np.concatenate([r_mat, np.zeros((1, r_mat.shape[1]), dtype=r_mat.dtype)], axis=0)
         good_components = s != 0
-        r_mat = r_mat[:, good_components]
-        s = s[good_components]
-        vt = vt[good_components, :]
-        lap("final_svd", t0)
+        if not np.all(good_components):
+            r_mat = r_mat[:, good_components]
+            s = s[good_components]
+            vt = vt[good_components, :]
+        lap("d2h_results", t0)
         display("Matrix decomposition completed")
 
         mean_img = mean_dev.cpu().numpy().reshape(d1, d2)
@@ -527,10 +601,9 @@ def localmd_decomposition(
             "seed": seed, "frames": list(frames), "thresholds": (float(spatial_threshold), float(temporal_threshold)),
             "sim_stats": sim_stats, "tile_ranks": ranks.astype(np.int32), "tile_stats": stats_dev.cpu().numpy(),
             "tile_good": good_dev.cpu().numpy(), "tile_keep": keep_dev.cpu().numpy(), "tile_lambda": lam_dev.cpu().numpy(),
-            "tile_ut": ut_host, "origins": origins, "pix": pix_c, "block_weights": block_weights,
+            "tile_ut": ut_dev.cpu().numpy(), "origins": origins, "pix": pix_c, "block_weights": block_weights,
             "max_components": r, "rank_before": R, "rank_after": rp, "timings": timings,
-            "spatial_basis": None if K <= 0 else basis_rows, "crop": crop, "dpad": dpad,
-            "p": P_dev[:, :rp].cpu().numpy(), "v_proj": Vp.cpu().numpy(),
+            "crop": crop, "dpad": dpad, "v_proj": Vp.cpu().numpy(),
         }
         return final_movie, diag
     finally:

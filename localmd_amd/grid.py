@@ -159,3 +159,48 @@ def cumulative_weights(fov, block_sizes, origins, block_weights):
     for k, j in origins:
         cw[k : k + b1, j : j + b2] += block_weights
     return cw
+
+
+def cover_tables(fov, block_sizes, dim_1_iters, dim_2_iters):
+    """cover1[i][0..3]: indices into dim_1_iters of the tile rows covering FOV row i (ascending,
+    -1 padded); cover2 likewise for columns.  int32 (d1, 4), (d2, 4)."""
+    out = []
+    for size, b, its in ((fov[0], block_sizes[0], dim_1_iters), (fov[1], block_sizes[1], dim_2_iters)):
+        cov = -np.ones((size, 4), dtype=np.int32)
+        fill = np.zeros(size, dtype=np.int64)
+        for idx, o in enumerate(its):
+            rows = np.arange(o, o + b)
+            if np.any(fill[rows] >= 4):
+                raise ValueError("a pixel is covered by more than 4 tile origins along one dimension")
+            cov[rows, fill[rows]] = idx
+            fill[rows] += 1
+        out.append(cov)
+    return out[0], out[1]
+
+
+def neighbour_lists(pairs, ranks, col_off, n_tiles, Rt, K):
+    """CSR-like lists for pmd_gram_apply: for tile a, every block of G in its block row:
+    (first M row of the block, rows in it, block index, flags) with flags bit0 = stored block is
+    (b, a) so it must be used transposed, bit1 = background block."""
+    a = pairs[:, 0].astype(np.int64)
+    b = pairs[:, 1].astype(np.int64)
+    idx = np.arange(pairs.shape[0], dtype=np.int64)
+    off_diag = a != b
+    rows = np.concatenate([a, b[off_diag]])
+    cols = np.concatenate([b, a[off_diag]])
+    blk = np.concatenate([idx, idx[off_diag]])
+    flg = np.concatenate([np.zeros(len(a), dtype=np.int64), np.ones(int(off_diag.sum()), dtype=np.int64)])
+    if K > 0:
+        t = np.arange(n_tiles, dtype=np.int64)
+        rows = np.concatenate([rows, t])
+        cols = np.concatenate([cols, np.full(n_tiles, -1, dtype=np.int64)])
+        blk = np.concatenate([blk, t])
+        flg = np.concatenate([flg, np.full(n_tiles, 2, dtype=np.int64)])
+    order = np.lexsort((cols, rows))
+    rows, cols, blk, flg = rows[order], cols[order], blk[order], flg[order]
+    row0 = np.where(cols >= 0, np.asarray(col_off)[np.maximum(cols, 0)], Rt)
+    nrow = np.where(cols >= 0, np.asarray(ranks)[np.maximum(cols, 0)], K)
+    nbr = np.stack([row0, nrow, blk, flg], axis=1).astype(np.int32)
+    ptr = np.zeros(n_tiles + 1, dtype=np.int64)
+    np.add.at(ptr, rows + 1, 1)
+    return np.cumsum(ptr).astype(np.int32), nbr

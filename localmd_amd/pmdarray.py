@@ -24,13 +24,20 @@ class PMDArray:
         self._r = r
         self._s = s
         self._v = v
-        # (R * s) V cached once: __getitem__ is then one sparse-dense product
-        self._combined_temporal = (self._r * self._s[None, :]).dot(self._v)
+        self._combined = None
         self.mean_img = mean_img
         self.var_img = std_img  # NB: a noise *std* estimate, stored under the reference's name
         self.row_indices = np.arange(self.fov_dim1 * self.fov_dim2).reshape(
             (self.fov_dim1, self.fov_dim2), order=self.order
         )
+
+    @property
+    def _combined_temporal(self):
+        """(R * s) V, built on first use and cached: __getitem__ is then one sparse-dense product
+        (the reference forms it eagerly in __init__, pmdarray.py:50-52)."""
+        if self._combined is None:
+            self._combined = (self._r * self._s[None, :]).dot(self._v)
+        return self._combined
 
     u = property(lambda self: self._u)
     r = property(lambda self: self._r)
