@@ -94,10 +94,10 @@ int pmd_threshold_sim(pmd_ctx* ctx, int b1, int b2, int t, int iters, uint64_t s
  * evaluation.py:84-222, decomposition.py:501-523).  Omega of tile b is logical array
  * (PMD_STREAM_TILE_OMEGA = 4, omega_index0 + b*omega_index_step).
  * pool_q[P][pool_max]: local pixels of pooling window p (-1 pads); pool_idx[q]: window of pixel q;
- * pool_w[q] = 1/|window|.  Outputs: Ut_out[n][64][dpad], V_out[n][64][ldv] (= sigma*V rows),
+ * pool_w[q] = 1/|window|.  n_rows = pixel rows of xf.  Outputs: Ut_out[n][64][dpad], V_out[n][64][ldv] (= sigma*V rows),
  * stats_out[n][64][2], good_out/keep_out[n][64], ranks_out[n], lam_out[n][64] (sigma^2, may be NULL). */
-size_t pmd_tiles_workspace_bytes(int n_tiles, int b1, int b2, int P, int r, int a, int t_crop, long ldv);
-int pmd_tiles_decompose(pmd_ctx* ctx, const float* xf, long ldx, int t_crop, const int* tile_pix, int n_tiles, int b1,
+size_t pmd_tiles_workspace_bytes(int n_tiles, int b1, int b2, int P, int r, int a, int t_crop, long ldv, long n_rows);
+int pmd_tiles_decompose(pmd_ctx* ctx, const float* xf, long ldx, long n_rows, int t_crop, const int* tile_pix, int n_tiles, int b1,
                         int b2, const int* pool_q, int pool_max, int P, const int* pool_idx, const float* pool_w, int r,
                         int a, float thr_s, float thr_t, int max_fail, uint64_t seed, uint32_t omega_index0,
                         uint32_t omega_index_step, float* Ut_out, float* V_out, long ldv, float* stats_out,
@@ -177,8 +177,9 @@ int pmdk_small_qr(pmd_ctx* ctx, const float* Yt, long y_tile_stride, int y_ld, i
                   long q_tile_stride, int q_ld, int n_tiles);
 int pmdk_small_eig(pmd_ctx* ctx, const double* G, int slices, int n, int mode, double tol, double* Nout,
                    double* lam_out, int n_tiles);
-int pmdk_tile_pool_bin(pmd_ctx* ctx, const float* X, long ldx, const int* pix, int n_tiles, int d, const int* pool_q,
-                       int pool_max, int P, int a, int nbins, float* abar, long ld_ab, long tile_stride);
+int pmdk_tile_pool_bin(pmd_ctx* ctx, const float* X, long ldx, long n_rows, const int* pix, int n_tiles, int d,
+                       const int* pool_q, int pool_max, int P, int a, int nbins, float* xbar, float* abar, long ld_ab,
+                       long tile_stride);
 int pmdk_roughness(pmd_ctx* ctx, const float* Ut, long u_tile_stride, int u_ld, int b1, int b2, const float* V,
                    long v_tile_stride, long v_ld, int T, int r, float* stats, int n_tiles);
 int pmdk_syevd(pmd_ctx* ctx, int n, float* A, long lda, float* w, float* work, int* info);

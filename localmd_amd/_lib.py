@@ -38,8 +38,8 @@ SIGNATURES = {
     "pmd_scale_rows": (c_i, [c_p, c_p, c_l, c_i, c_l, c_p]),
     "pmd_threshold_sim_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i]),
     "pmd_threshold_sim": (c_i, [c_p, c_i, c_i, c_i, c_i, c_u64, c_p, c_p, c_sz]),
-    "pmd_tiles_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_l]),
-    "pmd_tiles_decompose": (c_i, [c_p, c_p, c_l, c_i, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_f, c_f,
+    "pmd_tiles_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_l, c_l]),
+    "pmd_tiles_decompose": (c_i, [c_p, c_p, c_l, c_l, c_i, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_f, c_f,
                                   c_i, c_u64, c_u32, c_u32, c_p, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_sz]),
     "pmd_weight_tiles": (c_i, [c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_i]),
     "pmd_tiles_project": (c_i, [c_p, c_p, c_l, c_i, c_p, c_i, c_i, c_p, c_i, c_p, c_l, c_i]),
@@ -66,7 +66,7 @@ SIGNATURES = {
     "pmdk_tile_rowmix": (c_i, [c_p, c_p, c_l, c_l, c_p, c_l, c_i, c_i, c_p, c_l, c_l, c_i, c_i]),
     "pmdk_small_qr": (c_i, [c_p, c_p, c_l, c_i, c_i, c_i, c_p, c_l, c_i, c_i]),
     "pmdk_small_eig": (c_i, [c_p, c_p, c_i, c_i, c_i, c_d, c_p, c_p, c_i]),
-    "pmdk_tile_pool_bin": (c_i, [c_p, c_p, c_l, c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_l, c_l]),
+    "pmdk_tile_pool_bin": (c_i, [c_p, c_p, c_l, c_l, c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_l, c_l]),
     "pmdk_roughness": (c_i, [c_p, c_p, c_l, c_i, c_i, c_i, c_p, c_l, c_l, c_i, c_i, c_p, c_i]),
     "pmdk_syevd": (c_i, [c_p, c_i, c_p, c_l, c_p, c_p, c_p]),
 }

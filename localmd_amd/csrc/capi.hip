@@ -22,6 +22,7 @@ int pmd_ctx_create(int device, void* hip_stream, pmd_ctx** out) {
   ctx->blas = nullptr;
   ctx->err[0] = 0;
   ctx->profile = false;
+  ctx->atx_label = nullptr;
   if (rocblas_create_handle(&ctx->blas) != rocblas_status_success) { delete ctx; return PMD_ERR_BLAS; }
   rocblas_set_stream(ctx->blas, ctx->stream);
   rocblas_set_pointer_mode(ctx->blas, rocblas_pointer_mode_host);
@@ -155,16 +156,16 @@ int pmd_threshold_sim(pmd_ctx* ctx, int b1, int b2, int t, int iters, uint64_t s
   return pmd_threshold_sim_impl(ctx, b1, b2, t, iters, seed, stats_out, ws, ws_bytes);
 }
 
-size_t pmd_tiles_workspace_bytes(int n_tiles, int b1, int b2, int P, int r, int a, int t_crop, long ldv) {
-  return pmd_tiles_workspace_bytes_impl(n_tiles, b1 * b2, P, r, a, t_crop, ldv);
+size_t pmd_tiles_workspace_bytes(int n_tiles, int b1, int b2, int P, int r, int a, int t_crop, long ldv, long n_rows) {
+  return pmd_tiles_workspace_bytes_impl(n_tiles, b1 * b2, P, r, a, t_crop, ldv, n_rows);
 }
-int pmd_tiles_decompose(pmd_ctx* ctx, const float* xf, long ldx, int t_crop, const int* tile_pix, int n_tiles, int b1,
+int pmd_tiles_decompose(pmd_ctx* ctx, const float* xf, long ldx, long n_rows, int t_crop, const int* tile_pix, int n_tiles, int b1,
                         int b2, const int* pool_q, int pool_max, int P, const int* pool_idx, const float* pool_w, int r,
                         int a, float thr_s, float thr_t, int max_fail, uint64_t seed, uint32_t omega_index0,
                         uint32_t omega_index_step, float* Ut_out, float* V_out, long ldv, float* stats_out,
                         int* good_out, int* keep_out, int* ranks_out, double* lam_out, void* ws, size_t ws_bytes) {
   CTX_CHECK(ctx);
-  return pmd_tiles_decompose_impl(ctx, xf, ldx, t_crop, tile_pix, n_tiles, b1, b2, pool_q, pool_max, P, pool_idx,
+  return pmd_tiles_decompose_impl(ctx, xf, ldx, n_rows, t_crop, tile_pix, n_tiles, b1, b2, pool_q, pool_max, P, pool_idx,
                                   pool_w, r, a, thr_s, thr_t, max_fail, seed, omega_index0, omega_index_step, Ut_out,
                                   V_out, ldv, stats_out, good_out, keep_out, ranks_out, lam_out, ws, ws_bytes);
 }
@@ -178,7 +179,10 @@ int pmd_weight_tiles(pmd_ctx* ctx, const float* Ut, int dpad, const int* tile_pi
 int pmd_tiles_project(pmd_ctx* ctx, const float* x, long ldx, int T, const int* tile_pix, int n_tiles, int d,
                       const float* A, int dpad, float* Out, long ldo, int slices) {
   CTX_CHECK(ctx);
-  return pmd_launch_tile_atx(ctx, x, ldx, tile_pix, d, 0, d, A, 64L * dpad, dpad, Out, 64L * ldo, ldo, n_tiles, T, slices);
+  ctx->atx_label = "tile_atx_main";
+  const int rc = pmd_launch_tile_atx(ctx, x, ldx, tile_pix, d, 0, d, A, 64L * dpad, dpad, Out, 64L * ldo, ldo, n_tiles, T, slices);
+  ctx->atx_label = nullptr;
+  return rc;
 }
 
 int pmd_compact_rows(pmd_ctx* ctx, const float* Out, long ldo, const int* col_off, const int* ranks, int T, float* Z,
@@ -291,10 +295,11 @@ int pmdk_small_eig(pmd_ctx* ctx, const double* G, int slices, int n, int mode, d
   CTX_CHECK(ctx);
   return pmd_launch_small_eig(ctx, G, slices, n, mode, tol, Nout, lam_out, n_tiles);
 }
-int pmdk_tile_pool_bin(pmd_ctx* ctx, const float* X, long ldx, const int* pix, int n_tiles, int d, const int* pool_q,
-                       int pool_max, int P, int a, int nbins, float* abar, long ld_ab, long tile_stride) {
+int pmdk_tile_pool_bin(pmd_ctx* ctx, const float* X, long ldx, long n_rows, const int* pix, int n_tiles, int d,
+                       const int* pool_q, int pool_max, int P, int a, int nbins, float* xbar, float* abar, long ld_ab,
+                       long tile_stride) {
   CTX_CHECK(ctx);
-  return pmd_launch_tile_pool_bin(ctx, X, ldx, pix, n_tiles, d, pool_q, pool_max, P, a, nbins, abar, ld_ab, tile_stride);
+  return pmd_launch_tile_pool_bin(ctx, X, ldx, n_rows, pix, n_tiles, d, pool_q, pool_max, P, a, nbins, xbar, abar, ld_ab, tile_stride);
 }
 int pmdk_roughness(pmd_ctx* ctx, const float* Ut, long u_tile_stride, int u_ld, int b1, int b2, const float* V,
                    long v_tile_stride, long v_ld, int T, int r, float* stats, int n_tiles) {

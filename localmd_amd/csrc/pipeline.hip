@@ -25,7 +25,7 @@ long pmd_time_ld(long t) { return pmd_round_up(t, 64) + PMD_LD_SLACK; }
 struct tiles_plan {
   int nb, l, dpad, Ppad, nref;
   long ld_b;
-  float *abar, *omT, *yt, *qt, *bm, *udst, *ut0, *outA, *spart, *sst;
+  float *abar, *omT, *yt, *qt, *bm, *udst, *ut0, *outA, *spart, *sst, *xbar, *g1f;
   double *gpart, *nmat, *lam;
   size_t zero_bytes;  // leading part of the workspace that must be zeroed
 };
@@ -33,7 +33,7 @@ struct tiles_plan {
 static const int GRAM_SLICES = 4;
 static const int XBT_SLICES = 4;
 
-static int plan_tiles(pmd_arena& ar, tiles_plan& p, int n, int d, int P, int r, int a, int t_crop, long ldv) {
+static int plan_tiles(pmd_arena& ar, tiles_plan& p, int n, int d, int P, int r, int a, int t_crop, long ldv, long n_rows) {
   p.nb = t_crop / a;
   p.l = r + 10;
   p.dpad = pmd_tile_dpad(d);
@@ -52,6 +52,8 @@ static int plan_tiles(pmd_arena& ar, tiles_plan& p, int n, int d, int P, int r, 
   p.sst = ar.take_n<float>((size_t)n * 64 * p.dpad);
   p.zero_bytes = ar.used;
   p.bm = ar.take_n<float>((size_t)n * 64 * p.ld_b);
+  p.xbar = ar.take_n<float>((size_t)n_rows * p.ld_b);
+  p.g1f = ar.take_n<float>((size_t)n * GRAM_SLICES * 4096);
   p.outA = ar.take_n<float>((size_t)n * 64 * ldv);
   p.gpart = ar.take_n<double>((size_t)n * GRAM_SLICES * 4096);
   p.nmat = ar.take_n<double>((size_t)n * 4096);
@@ -59,14 +61,14 @@ static int plan_tiles(pmd_arena& ar, tiles_plan& p, int n, int d, int P, int r, 
   return PMD_OK;
 }
 
-size_t pmd_tiles_workspace_bytes_impl(int n, int d, int P, int r, int a, int t_crop, long ldv) {
+size_t pmd_tiles_workspace_bytes_impl(int n, int d, int P, int r, int a, int t_crop, long ldv, long n_rows) {
   pmd_arena ar((void*)0x1000, ~size_t(0) >> 1);
   tiles_plan p;
-  if (plan_tiles(ar, p, n, d, P, r, a, t_crop, ldv) != PMD_OK) return 0;
+  if (plan_tiles(ar, p, n, d, P, r, a, t_crop, ldv, n_rows) != PMD_OK) return 0;
   return ar.used + 4096;
 }
 
-int pmd_tiles_decompose_impl(pmd_ctx* ctx, const float* Xf, long ldx, int t_crop, const int* tile_pix, int n, int b1,
+int pmd_tiles_decompose_impl(pmd_ctx* ctx, const float* Xf, long ldx, long n_rows, int t_crop, const int* tile_pix, int n, int b1,
                              int b2, const int* pool_q, int pool_max, int P, const int* pool_idx, const float* pool_w,
                              int r, int a, float thr_s, float thr_t, int max_fail, uint64_t seed, uint32_t omega_index0,
                              uint32_t omega_index_step, float* Ut_out, float* V_out, long ldv, float* stats_out,
@@ -78,7 +80,7 @@ int pmd_tiles_decompose_impl(pmd_ctx* ctx, const float* Xf, long ldx, int t_crop
   if (ldv < pmd_time_ld(t_crop) || ldx < pmd_time_ld(t_crop)) return pmd_fail(ctx, PMD_ERR_ARG, "pmd_tiles_decompose", "leading dimension too small");
   pmd_arena ar(ws, ws_bytes);
   tiles_plan p;
-  if (plan_tiles(ar, p, n, d, P, r, a, t_crop, ldv) != PMD_OK)
+  if (plan_tiles(ar, p, n, d, P, r, a, t_crop, ldv, n_rows) != PMD_OK)
     return pmd_fail(ctx, PMD_ERR_UNSUPPORTED, "pmd_tiles_decompose", "tile too large (max 2048 pixels)");
   if (ar.overflow) return pmd_fail(ctx, PMD_ERR_WORKSPACE, "pmd_tiles_decompose", "workspace too small");
   if (r > p.nref) return pmd_fail(ctx, PMD_ERR_ARG, "pmd_tiles_decompose", "max_components exceeds pooled pixel count");
@@ -88,7 +90,7 @@ int pmd_tiles_decompose_impl(pmd_ctx* ctx, const float* Xf, long ldx, int t_crop
   PMD_HIP(ctx, hipMemsetAsync(Ut_out, 0, (size_t)n * s64d * sizeof(float), ctx->stream));
 
   // --- rSVD of the pooled, temporally binned tile (decomposition.py:279-294, :59-73)
-  RUN(pmd_launch_tile_pool_bin(ctx, Xf, ldx, tile_pix, n, d, pool_q, pool_max, P, a, p.nb, p.abar, p.ld_b, (long)P * p.ld_b));
+  RUN(pmd_launch_tile_pool_bin(ctx, Xf, ldx, n_rows, tile_pix, n, d, pool_q, pool_max, P, a, p.nb, p.xbar, p.abar, p.ld_b, (long)P * p.ld_b));
   for (int t0 = 0; t0 < n; t0 += 32768) {
     const int tn = (n - t0 < 32768) ? n - t0 : 32768;
     RUN(pmd_launch_rng(ctx, seed, PMD_STREAM_TILE_OMEGA, omega_index0 + (uint32_t)t0 * omega_index_step,
@@ -103,8 +105,11 @@ int pmd_tiles_decompose_impl(pmd_ctx* ctx, const float* Xf, long ldx, int t_crop
   RUN(pmd_launch_expand_pooled(ctx, p.udst, s64P, p.Ppad, pool_idx, pool_w, d, r, p.ut0, s64d, p.dpad, n));
 
   // --- V_ds = U_ds^T X_ds; basis of its row space (decomposition.py:295-301)
+  ctx->atx_label = "tile_atx_main";
   RUN(pmd_launch_tile_atx(ctx, Xf, ldx, tile_pix, d, 0, d, p.ut0, s64d, p.dpad, p.outA, s64v, ldv, n, t_crop, 2));
-  RUN(pmd_launch_tile_gram(ctx, p.outA, s64v, ldv, t_crop, n, GRAM_SLICES, p.gpart));
+  // (this Gram only conditions the basis change -- span(S) does not depend on it -- so fp32 MFMA is enough)
+  RUN(pmd_launch_tile_xbt(ctx, p.outA, ldv, nullptr, 0, 64, 64, p.outA, s64v, ldv, p.g1f, GRAM_SLICES * 4096L, 4096, 64, n, t_crop, GRAM_SLICES));
+  RUN(pmd_launch_gram_f2d(ctx, p.g1f, 64, (long)n * GRAM_SLICES, p.gpart));
   RUN(pmd_launch_small_eig(ctx, p.gpart, GRAM_SLICES, r, 1, 1e-10, p.nmat, p.lam, n));
 
   // --- S = X V_b^T and its left singular vectors U0 (decomposition.py:304-317)
@@ -117,6 +122,7 @@ int pmd_tiles_decompose_impl(pmd_ctx* ctx, const float* Xf, long ldx, int t_crop
 
   // --- W = U0^T X, its SVD rotates U0 and gives sigma*V (decomposition.py:318-323)
   RUN(pmd_launch_tile_atx(ctx, Xf, ldx, tile_pix, d, 0, d, p.sst, s64d, p.dpad, V_out, s64v, ldv, n, t_crop, 2));
+  ctx->atx_label = nullptr;
   RUN(pmd_launch_tile_gram(ctx, V_out, s64v, ldv, t_crop, n, GRAM_SLICES, p.gpart));
   RUN(pmd_launch_small_eig(ctx, p.gpart, GRAM_SLICES, r, 0, 0.0, p.nmat, sing_out ? sing_out : p.lam, n));
   RUN(pmd_launch_tile_rowmix(ctx, p.sst, s64d, p.dpad, p.nmat, 4096, r, r, Ut_out, s64d, p.dpad, d, n));

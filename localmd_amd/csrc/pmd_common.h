@@ -35,6 +35,7 @@ struct pmd_ctx {
   rocblas_handle blas;
   float* tables;  // device: Hann window + FFT twiddles, see prep.hip
   char err[512];
+  const char* atx_label;             // profiling name of the next tile_atx launches (NULL: "tile_atx")
   bool profile;                      // pmd_profile_enable: HIP events around every kernel group
   std::vector<pmd_prof_rec> recs;
 };

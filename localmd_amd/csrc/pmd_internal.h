@@ -21,9 +21,9 @@ int pmd_launch_standardize_transpose(pmd_ctx* ctx, const float* movie, long D, c
 int pmd_launch_filter(pmd_ctx* ctx, const float* in, float* out, long D, int nf, long ld, const float* basis, int K,
                       const float* pj, long ldp);
 int pmd_launch_scale_rows(pmd_ctx* ctx, float* x, long D, int nf, long ld, const float* w);
-int pmd_launch_tile_pool_bin(pmd_ctx* ctx, const float* X, long ldx, const int* pix, int n_tiles, int d,
-                             const int* pool_q, int pool_max, int P, int a, int nbins, float* abar, long ld_ab,
-                             long tile_stride);
+int pmd_launch_tile_pool_bin(pmd_ctx* ctx, const float* X, long ldx, long n_rows, const int* pix, int n_tiles, int d,
+                             const int* pool_q, int pool_max, int P, int a, int nbins, float* xbar, float* abar,
+                             long ld_ab, long tile_stride);
 
 // tile_gemm.hip
 int pmd_launch_tile_atx(pmd_ctx* ctx, const float* X, long ldx, const int* pix, int pix_stride, long row0_stride, int d,
@@ -34,6 +34,7 @@ int pmd_launch_tile_xbt(pmd_ctx* ctx, const float* X, long ldx, const int* pix, 
                         long s_slice_stride, int s_ld, int n_tiles, int T, int slices);
 int pmd_launch_tile_gram(pmd_ctx* ctx, const float* In, long tile_stride, long ld, int len, int n_tiles, int slices,
                          double* G);
+int pmd_launch_gram_f2d(pmd_ctx* ctx, const float* in, int ld, long n_blocks, double* out);
 int pmd_launch_reduce_slices(pmd_ctx* ctx, const float* in, long tile_stride, long slice_stride, int slices, long n,
                              float* out, long out_tile_stride, int n_tiles);
 int pmd_launch_tile_rowmix(pmd_ctx* ctx, const float* In, long in_tile_stride, long ld_in, const double* N,
@@ -54,8 +55,8 @@ int pmd_launch_decide(pmd_ctx* ctx, const float* stats, int r, float thr_s, floa
                       int n_tiles, int* good, int* keep, int* ranks);
 
 // pipeline.hip
-size_t pmd_tiles_workspace_bytes_impl(int n, int d, int P, int r, int a, int t_crop, long ldv);
-int pmd_tiles_decompose_impl(pmd_ctx* ctx, const float* Xf, long ldx, int t_crop, const int* tile_pix, int n, int b1,
+size_t pmd_tiles_workspace_bytes_impl(int n, int d, int P, int r, int a, int t_crop, long ldv, long n_rows);
+int pmd_tiles_decompose_impl(pmd_ctx* ctx, const float* Xf, long ldx, long n_rows, int t_crop, const int* tile_pix, int n, int b1,
                              int b2, const int* pool_q, int pool_max, int P, const int* pool_idx, const float* pool_w,
                              int r, int a, float thr_s, float thr_t, int max_fail, uint64_t seed, uint32_t omega_index0,
                              uint32_t omega_index_step, float* Ut_out, float* V_out, long ldv, float* stats_out,

@@ -266,42 +266,61 @@ int pmd_launch_scale_rows(pmd_ctx* ctx, float* x, long D, int nf, long ld, const
 }
 
 // ---- pooled + temporally binned sketch matrix of every tile (decomposition.py:279-290) -----
-// abar[tile][p][cbin] = (1/|window p|) * sum_{q in window p} mean_{tau in bin} X[pix[tile][q]][a*cbin + tau]
-// pool_q: [P][pool_max] local pixel ids of window p (-1 = padding); rows p in [P, Ppad) are zero.
-__global__ __launch_bounds__(256) void tile_pool_bin_kernel(const float* __restrict__ X, long ldx,
-                                                            const int* __restrict__ pix, int d,
-                                                            const int* __restrict__ pool_q, int pool_max, int P,
-                                                            int a, int nbins, float* __restrict__ abar, long ld_ab,
-                                                            long tile_stride) {
+// Two steps so that the full-resolution movie is read once, coalesced:
+//   xbar[c][cb]          = mean_{tau < a} X[c][a*cb + tau]                       (bin_average)
+//   abar[tile][p][cb]    = (1/|window p|) * sum_{q in window p} xbar[pix[tile][q]][cb]   (tile_pool)
+// pool_q: [P][pool_max] local pixel ids of window p (-1 = padding).
+__global__ __launch_bounds__(256) void bin_average_kernel(const float* __restrict__ X, long ldx, int a, int nbins,
+                                                          float* __restrict__ xbar, long ldb) {
+  const long c = blockIdx.y;
+  const float inv = 1.0f / (float)a;
+  for (int cb = blockIdx.x * blockDim.x + threadIdx.x; cb < nbins; cb += gridDim.x * blockDim.x) {
+    const float* row = X + c * ldx + (long)cb * a;
+    float s = 0.f;
+    for (int tau = 0; tau < a; ++tau) s += row[tau];
+    xbar[c * ldb + cb] = s * inv;
+  }
+}
+
+__global__ __launch_bounds__(256) void tile_pool_kernel(const float* __restrict__ xbar, long ldb,
+                                                        const int* __restrict__ pix, int d,
+                                                        const int* __restrict__ pool_q, int pool_max, int P, int nbins,
+                                                        float* __restrict__ abar, long ld_ab, long tile_stride) {
   const int tile = blockIdx.y;
   const int p = blockIdx.z;
   const int* pq = pool_q + (long)p * pool_max;
   const int* px = pix + (long)tile * d;
   int cnt = 0;
   for (int w = 0; w < pool_max; ++w) cnt += (pq[w] >= 0);
-  const float inv = 1.0f / (float)(cnt * a);
+  const float inv = 1.0f / (float)cnt;
   for (int cb = blockIdx.x * blockDim.x + threadIdx.x; cb < nbins; cb += gridDim.x * blockDim.x) {
     float s = 0.f;
     for (int w = 0; w < pool_max; ++w) {
       const int q = pq[w];
-      if (q < 0) continue;
-      const float* row = X + (long)px[q] * ldx + (long)cb * a;
-      for (int tau = 0; tau < a; ++tau) s += row[tau];
+      if (q >= 0) s += xbar[(long)px[q] * ldb + cb];
     }
     abar[(long)tile * tile_stride + (long)p * ld_ab + cb] = s * inv;
   }
 }
 
-int pmd_launch_tile_pool_bin(pmd_ctx* ctx, const float* X, long ldx, const int* pix, int n_tiles, int d,
-                             const int* pool_q, int pool_max, int P, int a, int nbins, float* abar, long ld_ab,
-                             long tile_stride) {
+// xbar: n_rows x ld_ab scratch (n_rows = pixel rows of X)
+int pmd_launch_tile_pool_bin(pmd_ctx* ctx, const float* X, long ldx, long n_rows, const int* pix, int n_tiles, int d,
+                             const int* pool_q, int pool_max, int P, int a, int nbins, float* xbar, float* abar,
+                             long ld_ab, long tile_stride) {
   pmd_prof_scope prof__(ctx, "tile_pool_bin");
   int bx = (nbins + 255) / 256;
+  if (bx > 8) bx = 8;
+  for (long c0 = 0; c0 < n_rows; c0 += 32768) {
+    const long cn = (n_rows - c0 < 32768) ? n_rows - c0 : 32768;
+    hipLaunchKernelGGL(bin_average_kernel, dim3(bx, (unsigned)cn), dim3(256), 0, ctx->stream, X + c0 * ldx, ldx, a, nbins,
+                       xbar + c0 * ld_ab, ld_ab);
+    PMD_LAUNCH_CHECK(ctx, "bin_average_kernel");
+  }
   for (int t0 = 0; t0 < n_tiles; t0 += 32768) {
     const int tn = (n_tiles - t0 < 32768) ? n_tiles - t0 : 32768;
-    hipLaunchKernelGGL(tile_pool_bin_kernel, dim3(bx, tn, P), dim3(256), 0, ctx->stream, X, ldx, pix + (long)t0 * d, d,
-                       pool_q, pool_max, P, a, nbins, abar + (long)t0 * tile_stride, ld_ab, tile_stride);
-    PMD_LAUNCH_CHECK(ctx, "tile_pool_bin_kernel");
+    hipLaunchKernelGGL(tile_pool_kernel, dim3(bx, tn, P), dim3(256), 0, ctx->stream, xbar, ld_ab, pix + (long)t0 * d, d,
+                       pool_q, pool_max, P, nbins, abar + (long)t0 * tile_stride, ld_ab, tile_stride);
+    PMD_LAUNCH_CHECK(ctx, "tile_pool_kernel");
   }
   return PMD_OK;
 }

@@ -165,7 +165,7 @@ static int launch_atx_variant(pmd_ctx* ctx, const float* X, long ldx, const int*
 int pmd_launch_tile_atx(pmd_ctx* ctx, const float* X, long ldx, const int* pix, int pix_stride, long row0_stride, int d,
                         const float* A, long a_tile_stride, int a_ld, float* Out, long out_tile_stride, long ldo,
                         int n_tiles, int T, int slices) {
-  pmd_prof_scope prof__(ctx, "tile_atx");
+  pmd_prof_scope prof__(ctx, ctx->atx_label ? ctx->atx_label : "tile_atx");
   if (n_tiles <= 0 || T <= 0) return PMD_OK;
   int kz = 1;
   int dv = d;
@@ -289,11 +289,19 @@ int pmd_launch_tile_xbt(pmd_ctx* ctx, const float* X, long ldx, const int* pix, 
   slices = (n_groups + gps - 1) / gps;
   const int mtiles = (d + 15) / 16;
   if (s_ld < 16 * mtiles) return pmd_fail(ctx, PMD_ERR_ARG, "tile_xbt", "s_ld too small");
-  constexpr int MPW = 7;
-  const int mblocks = (mtiles + 4 * MPW - 1) / (4 * MPW);
-  hipLaunchKernelGGL(tile_xbt_kernel<MPW>, dim3(n_tiles, slices, mblocks), dim3(256), 0, ctx->stream, X, ldx, pix,
-                     pix_stride, row0_stride, d, B, b_tile_stride, ldb, S, s_tile_stride, s_slice_stride, s_ld,
-                     n_groups, gps);
+  // M tiles per wave: spread small tiles over the four waves, 7 per wave (112 accumulator VGPRs) at most
+#define XBT_LAUNCH(MPW_)                                                                                              \
+  {                                                                                                                   \
+    const int mblocks = (mtiles + 4 * MPW_ - 1) / (4 * MPW_);                                                         \
+    hipLaunchKernelGGL(tile_xbt_kernel<MPW_>, dim3(n_tiles, slices, mblocks), dim3(256), 0, ctx->stream, X, ldx, pix, \
+                       pix_stride, row0_stride, d, B, b_tile_stride, ldb, S, s_tile_stride, s_slice_stride, s_ld,     \
+                       n_groups, gps);                                                                                \
+  }
+  if (mtiles <= 4) XBT_LAUNCH(1)
+  else if (mtiles <= 8) XBT_LAUNCH(2)
+  else if (mtiles <= 16) XBT_LAUNCH(4)
+  else XBT_LAUNCH(7)
+#undef XBT_LAUNCH
   PMD_LAUNCH_CHECK(ctx, "tile_xbt_kernel");
   return PMD_OK;
 }
@@ -439,5 +447,21 @@ int pmd_launch_tile_rowmix(pmd_ctx* ctx, const float* In, long in_tile_stride, l
                          n_tile_stride, n_in, n_out, out, out_tile_stride, ld_out, len);
     PMD_LAUNCH_CHECK(ctx, "tile_rowmix_kernel");
   }
+  return PMD_OK;
+}
+
+// float partial Gram blocks (tile_xbt output, [tile][slice][64][ld]) -> double [tile][slice][64][64]
+__global__ void gram_f2d_kernel(const float* __restrict__ in, int ld, long n_blocks, double* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_blocks * 4096) return;
+  const long b = i >> 12;
+  const int r = (int)((i >> 6) & 63), c = (int)(i & 63);
+  out[i] = (double)in[b * 64 * ld + (long)r * ld + c];
+}
+
+int pmd_launch_gram_f2d(pmd_ctx* ctx, const float* in, int ld, long n_blocks, double* out) {
+  hipLaunchKernelGGL(gram_f2d_kernel, dim3((unsigned)((n_blocks * 4096 + 255) / 256)), dim3(256), 0, ctx->stream, in, ld,
+                     n_blocks, out);
+  PMD_LAUNCH_CHECK(ctx, "gram_f2d_kernel");
   return PMD_OK;
 }

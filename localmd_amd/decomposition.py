@@ -405,8 +405,8 @@ def localmd_decomposition(
         keep_dev = torch.zeros((n_tiles, 64), dtype=torch.int32, device=ctx.device)
         ranks_dev = torch.zeros((n_tiles,), dtype=torch.int32, device=ctx.device)
         lam_dev = torch.zeros((n_tiles, 64), dtype=torch.float64, device=ctx.device)
-        ws = ctx.workspace(lib.pmd_tiles_workspace_bytes(n_tiles, b1, b2, P_pool, r, int(temporal_avg_factor), crop, ldv))
-        ctx.call("pmd_tiles_decompose", ptr(xf), ld_f, crop, ptr(pix_dev), n_tiles, b1, b2, ptr(pool_q_dev),
+        ws = ctx.workspace(lib.pmd_tiles_workspace_bytes(n_tiles, b1, b2, P_pool, r, int(temporal_avg_factor), crop, ldv, D))
+        ctx.call("pmd_tiles_decompose", ptr(xf), ld_f, D, crop, ptr(pix_dev), n_tiles, b1, b2, ptr(pool_q_dev),
                  pool_q.shape[1], P_pool, ptr(pool_idx_dev), ptr(pool_w_dev), r, int(temporal_avg_factor),
                  float(np.float32(spatial_threshold)), float(np.float32(temporal_threshold)),
                  int(max_consecutive_failures), seed, 0, 1, ptr(ut_dev), ptr(v_dev), ldv, ptr(stats_dev), ptr(good_dev),

@@ -244,8 +244,10 @@ def test_pool_bin(gpu_ctx):
     nb = T // a
     ldb = ctx.lib.pmd_time_ld(nb)
     ab = torch.zeros((n, Pn, ldb), dtype=torch.float32, device=ctx.device)
+    xbar = torch.zeros((d1 * d2, ldb), dtype=torch.float32, device=ctx.device)
     Xd, pd, pq = dev(ctx, X), dev(ctx, pix), dev(ctx, pool_q)
-    ctx.call("pmdk_tile_pool_bin", P(Xd), ld, P(pd), n, b1 * b2, P(pq), pool_q.shape[1], Pn, a, nb, P(ab), ldb, Pn * ldb)
+    ctx.call("pmdk_tile_pool_bin", P(Xd), ld, d1 * d2, P(pd), n, b1 * b2, P(pq), pool_q.shape[1], Pn, a, nb, P(xbar), P(ab),
+             ldb, Pn * ldb)
     ctx.sync()
     got = ab.cpu().numpy()[:, :, :nb]
     mov = X[:, :T].reshape(d1, d2, T)

@@ -157,9 +157,9 @@ def _run_tiles(ctx, xf_np, d1, d2, b1, b2, r, a, thr, seed):
     keep = torch.zeros((n, 64), dtype=torch.int32, device=ctx.device)
     ranks = torch.zeros((n,), dtype=torch.int32, device=ctx.device)
     lam = torch.zeros((n, 64), dtype=torch.float64, device=ctx.device)
-    ws = ctx.workspace(lib.pmd_tiles_workspace_bytes(n, b1, b2, Pn, r, a, Tc, ld))
+    ws = ctx.workspace(lib.pmd_tiles_workspace_bytes(n, b1, b2, Pn, r, a, Tc, ld, D))
     pix_d, pq_d, pi_d, pw_d = dev(ctx, pix), dev(ctx, pool_q), dev(ctx, pool_idx), dev(ctx, pool_w)
-    ctx.call("pmd_tiles_decompose", P(xf), ld, Tc, P(pix_d), n, b1, b2, P(pq_d), pool_q.shape[1], Pn,
+    ctx.call("pmd_tiles_decompose", P(xf), ld, D, Tc, P(pix_d), n, b1, b2, P(pq_d), pool_q.shape[1], Pn,
              P(pi_d), P(pw_d), r, a, float(thr[0]), float(thr[1]), 1, seed, 0, 1, P(ut), P(v), ld,
              P(stats), P(good), P(keep), P(ranks), P(lam), P(ws), ws.numel())
     ctx.sync()

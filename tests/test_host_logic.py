@@ -255,7 +255,7 @@ def test_library_exports_every_declared_symbol():
     assert loaded.pmd_tile_dpad(400) == 400 and loaded.pmd_tile_dpad(100) == 256 and loaded.pmd_tile_dpad(1024) == 1024
     assert loaded.pmd_tile_dpad(1600) == 2048 and loaded.pmd_tile_dpad(3000) == -1
     assert loaded.pmd_time_ld(10000) == 10048 + 64 and loaded.pmd_time_ld(64) == 128
-    assert loaded.pmd_tiles_workspace_bytes(2601, 20, 20, 100, 50, 10, 10000, 10112) > 0
+    assert loaded.pmd_tiles_workspace_bytes(2601, 20, 20, 100, 50, 10, 10000, 10112, 262144) > 0
 
 
 def test_product_fails_loudly_without_gpu():
