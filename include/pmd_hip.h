@@ -144,6 +144,11 @@ int pmd_gram_apply(pmd_ctx* ctx, const float* Gblk, const float* Gbg, const floa
 size_t pmd_orthogonalize_factored_workspace_bytes(int m);
 int pmd_orthogonalize_factored(pmd_ctx* ctx, const float* M, int Rc, int m, long ldm, const float* GM, long ldgm,
                                float* Et_out, long lde, int* rprime_host, void* ws, size_t ws_bytes);
+/* Cholesky variant of the same step: Et = U_c^{-T} with M^T G M = U_c^T U_c.  P = M Et^T differs from the
+ * eigenvector form by an orthogonal factor that the projected SVD absorbs, so R, s, Vt are unchanged.
+ * *ok_host = 0 if the matrix is not numerically positive definite (use pmd_orthogonalize_factored then). */
+int pmd_orthogonalize_chol(pmd_ctx* ctx, const float* M, int Rc, int m, long ldm, const float* GM, long ldgm,
+                           float* Et_out, long lde, int* ok_host, void* ws, size_t ws_bytes);
 size_t pmd_projected_svd_factored_workspace_bytes(int m, int rp, int T);
 int pmd_projected_svd_factored(pmd_ctx* ctx, const float* M, int Rc, int m, long ldm, const float* Et, int rp, long lde,
                                const float* Z, int T, long ldz, float* R_out, long ldr, float* s_out, float* Vt_out,

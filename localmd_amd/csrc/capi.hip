@@ -252,6 +252,11 @@ int pmd_orthogonalize_factored(pmd_ctx* ctx, const float* M, int Rc, int m, long
   CTX_CHECK(ctx);
   return pmd_orthogonalize_factored_impl(ctx, M, Rc, m, ldm, GM, ldgm, Et_out, lde, rprime_host, ws, ws_bytes);
 }
+int pmd_orthogonalize_chol(pmd_ctx* ctx, const float* M, int Rc, int m, long ldm, const float* GM, long ldgm,
+                           float* Et_out, long lde, int* ok_host, void* ws, size_t ws_bytes) {
+  CTX_CHECK(ctx);
+  return pmd_orthogonalize_chol_impl(ctx, M, Rc, m, ldm, GM, ldgm, Et_out, lde, ok_host, ws, ws_bytes);
+}
 size_t pmd_projected_svd_factored_workspace_bytes(int m, int rp, int T) {
   return pmd_projected_svd_factored_workspace_bytes_impl(m, rp, T);
 }

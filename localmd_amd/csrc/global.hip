@@ -806,3 +806,45 @@ int pmd_projected_svd_factored_impl(pmd_ctx* ctx, const float* M, int Rc, int m,
   RUN(pmd_gemm_rm(ctx, 0, 0, Rc, rp, m, 1.f, M, ldm, X1, rp, 0.f, R_out, ldr));
   return PMD_OK;
 }
+
+// =============================================================================================
+// Cholesky form of the orthogonalisation (R > frames): any P with the column space of `right` and
+// P^T G P = I gives the same final R, s, Vt (P_chol = P_eigh Q with Q orthogonal, and the
+// projected SVD absorbs Q).  C = M^T G M = U_c^T U_c (upper Cholesky), P = M U_c^{-1}, i.e.
+// Et = U_c^{-T} (lower triangular).  ok_host = 0 when C is not numerically positive definite
+// (the caller then uses the eigendecomposition, decomposition.py:984-996).
+// =============================================================================================
+__global__ void tril_mask_kernel(float* __restrict__ A, long ld, int n) {
+  const int i = blockIdx.y;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x)
+    if (j > i) A[(long)i * ld + j] = 0.f;
+}
+
+int pmd_orthogonalize_chol_impl(pmd_ctx* ctx, const float* M, int Rc, int m, long ldm, const float* GM, long ldgm,
+                                float* Et_out, long lde, int* ok_host, void* ws, size_t ws_bytes) {
+  pmd_arena ar(ws, ws_bytes);
+  int* info = ar.take_n<int>(4);
+  if (ar.overflow) return pmd_fail(ctx, PMD_ERR_WORKSPACE, "pmd_orthogonalize_chol", "workspace too small");
+  *ok_host = 0;
+  RUN(pmd_gemm_rm(ctx, 1, 0, m, m, Rc, 1.f, M, ldm, GM, ldgm, 0.f, Et_out, lde));
+  int hinfo = 0;
+  {
+    pmd_prof_scope prof__(ctx, "rocsolver_spotrf");
+    PMD_BLAS(ctx, rocsolver_spotrf(ctx->blas, rocblas_fill_upper, m, Et_out, (rocblas_int)lde, info));
+  }
+  PMD_HIP(ctx, hipMemcpyAsync(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  PMD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (hinfo != 0) return PMD_OK;  // not positive definite: ok_host stays 0
+  {
+    pmd_prof_scope prof__(ctx, "rocsolver_strtri");
+    PMD_BLAS(ctx, rocsolver_strtri(ctx->blas, rocblas_fill_upper, rocblas_diagonal_non_unit, m, Et_out, (rocblas_int)lde, info));
+  }
+  PMD_HIP(ctx, hipMemcpyAsync(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  // column-major upper U^{-1} == row-major lower U^{-T} = Et; clear the other triangle (old C entries)
+  hipLaunchKernelGGL(tril_mask_kernel, dim3(8, m), dim3(256), 0, ctx->stream, Et_out, lde, m);
+  PMD_LAUNCH_CHECK(ctx, "tril_mask_kernel");
+  PMD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (hinfo != 0) return PMD_OK;
+  *ok_host = 1;
+  return PMD_OK;
+}

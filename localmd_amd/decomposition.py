@@ -8,7 +8,11 @@ used for device memory, streams and H2D/D2H copies only.  There is no CPU fallba
 
 Additions to the reference signature (keyword-only): ``seed`` (counter-based device RNG seed;
 default: one draw from np.random), ``device`` (HIP device index), ``thresholds`` (inject the
-two roughness cut-offs instead of simulating them), ``sim_iters``, ``return_diagnostics``.
+two roughness cut-offs instead of simulating them), ``sim_iters``, ``return_diagnostics``,
+``orthogonalizer``: how the mixing matrix P with (UP)^T(UP) = I is built when R > frames --
+"eigh" is the reference's eigendecomposition (decomposition.py:984-996); "cholesky" uses the
+Cholesky factor of the same Gram matrix (P differs by an orthogonal factor that the final SVD
+absorbs, so R, s, Vt are the same); "auto" (default) = cholesky with eigh as fallback.
 """
 import datetime
 import math
@@ -247,6 +251,7 @@ def localmd_decomposition(
     device: Optional[int] = None,
     thresholds=None,
     sim_iters: int = 250,
+    orthogonalizer: str = "auto",
     return_diagnostics: bool = False,
     ctx: Optional[Context] = None,
 ):
@@ -257,6 +262,8 @@ def localmd_decomposition(
         raise NotImplementedError("spatial_denoiser / temporal_denoiser hooks are not available in the HIP pipeline")
     if order not in ("F", "C"):
         raise ValueError("order must be 'F' or 'C'")
+    if orthogonalizer not in ("auto", "eigh", "cholesky"):
+        raise ValueError("orthogonalizer must be 'auto', 'eigh' or 'cholesky'")
     timings = {}
     t_start = time.perf_counter()
 
@@ -496,6 +503,7 @@ def localmd_decomposition(
         use_right = R > m_cols  # decomposition.py:976 (R counts the placeholder column too)
         _dbg("v_cropped", vc)
         P_dev = Et_dev = None
+        chol_ok = False
         if use_right:
             # P = right E / sqrt(lambda) stays factored; G = U^T U stays block-sparse
             n_pairs = pairs.shape[0]
@@ -507,16 +515,50 @@ def localmd_decomposition(
                      ptr(gstrip), Rc)
             nbr_ptr, nbr = grid.neighbour_lists(pairs, ranks, offsets[:-1], n_tiles, Rt, max(K, 0))
             nbr_ptr_dev, nbr_dev = _i32(ctx, nbr_ptr), _i32(ctx, nbr)
+            ld_right = m_cols
             GM = torch.empty((Rc, m_cols), dtype=torch.float32, device=ctx.device)
-            ctx.call("pmd_gram_apply", ptr(gblk), ptr(gbg), ptr(gstrip), Rc, ptr(nbr_ptr_dev), ptr(nbr_dev), ptr(col_off_dev),
-                     ptr(ranks_dev), n_tiles, Rt, max(K, 0), int(ranks.max()) if n_tiles else 0, ptr(right), m_cols, m_cols,
-                     ptr(GM), m_cols)
             Et_dev = torch.empty((m_cols, m_cols), dtype=torch.float32, device=ctx.device)
-            ws = ctx.workspace(lib.pmd_orthogonalize_factored_workspace_bytes(m_cols))
-            rp_c = c_i(0)
-            ctx.call("pmd_orthogonalize_factored", ptr(right), Rc, m_cols, m_cols, ptr(GM), m_cols, ptr(Et_dev), m_cols,
-                     C.byref(rp_c), ptr(ws), ws.numel())
-            rp = int(rp_c.value)
+
+            def gram_apply(ncols):
+                ctx.call("pmd_gram_apply", ptr(gblk), ptr(gbg), ptr(gstrip), Rc, ptr(nbr_ptr_dev), ptr(nbr_dev),
+                         ptr(col_off_dev), ptr(ranks_dev), n_tiles, Rt, max(K, 0), int(ranks.max()) if n_tiles else 0,
+                         ptr(right), ld_right, ncols, ptr(GM), m_cols)
+
+            chol_ok = False
+            if orthogonalizer in ("auto", "cholesky"):
+                m_eff = m_cols
+                if all_frames and not rank_prune and pixel_weighting is None:
+                    # Every standardised trace sums to ~0 over the frames it was centred on, so the constant
+                    # vector is a numerically null right vector of v_cropped.  Rotate it into the last column
+                    # (Householder H, H e_m = 1/sqrt(m)) and drop that column: same column space of U right.
+                    nhat = np.full(m_cols, 1.0 / math.sqrt(m_cols))
+                    hv = -nhat
+                    hv[-1] += 1.0
+                    hv /= np.linalg.norm(hv)
+                    hv_dev = _f32(ctx, hv)
+                    y_dev = torch.empty((Rc, 1), dtype=torch.float32, device=ctx.device)
+                    ctx.call("pmd_gemm", 0, 0, Rc, 1, m_cols, 1.0, ptr(right), ld_right, ptr(hv_dev), 1, 0.0, ptr(y_dev), 1)
+                    ctx.call("pmd_gemm", 0, 0, Rc, m_cols, 1, -2.0, ptr(y_dev), 1, ptr(hv_dev), m_cols, 1.0, ptr(right), ld_right)
+                    m_eff = m_cols - 1
+                gram_apply(m_eff)
+                ok_c = c_i(0)
+                ws = ctx.workspace(4096)
+                ctx.call("pmd_orthogonalize_chol", ptr(right), Rc, m_eff, ld_right, ptr(GM), m_cols, ptr(Et_dev), m_cols,
+                         C.byref(ok_c), ptr(ws), ws.numel())
+                chol_ok = bool(ok_c.value)
+                if chol_ok:
+                    rp = m_eff
+                    m_used = m_eff
+                elif orthogonalizer == "cholesky":
+                    raise PMDLibraryError("orthogonalizer='cholesky': U^T U restricted to the right matrix is not positive definite")
+            if not chol_ok:
+                gram_apply(m_cols)
+                ws = ctx.workspace(lib.pmd_orthogonalize_factored_workspace_bytes(m_cols))
+                rp_c = c_i(0)
+                ctx.call("pmd_orthogonalize_factored", ptr(right), Rc, m_cols, ld_right, ptr(GM), m_cols, ptr(Et_dev), m_cols,
+                         C.byref(rp_c), ptr(ws), ws.numel())
+                rp = int(rp_c.value)
+                m_used = m_cols
             del GM, gblk, gbg
         else:
             G = torch.empty((Rc, Rc), dtype=torch.float32, device=ctx.device)
@@ -563,13 +605,13 @@ def localmd_decomposition(
             R_out = torch.empty((Rc, nk), dtype=torch.float32, device=ctx.device)
             s_out = torch.empty((nk,), dtype=torch.float32, device=ctx.device)
             Vt_out = torch.empty((nk, T), dtype=torch.float32, device=ctx.device)
-            ws = ctx.workspace(lib.pmd_projected_svd_factored_workspace_bytes(m_cols, rp, T))
-            ctx.call("pmd_projected_svd_factored", ptr(right), Rc, m_cols, m_cols, ptr(Et_dev), rp, m_cols, ptr(Z), T, T,
+            ws = ctx.workspace(lib.pmd_projected_svd_factored_workspace_bytes(m_used, rp, T))
+            ctx.call("pmd_projected_svd_factored", ptr(right), Rc, m_used, m_cols, ptr(Et_dev), rp, m_cols, ptr(Z), T, T,
                      ptr(R_out), nk, ptr(s_out), ptr(Vt_out), T, ptr(Vp), T, ptr(ws), ws.numel())
         else:
             if P_dev is None:  # factored P with R' > T (rank_prune corner): materialise P = right Et^T
                 P_dev = torch.empty((Rc, m_cols), dtype=torch.float32, device=ctx.device)
-                ctx.call("pmd_gemm", 0, 1, Rc, rp, m_cols, 1.0, ptr(right), m_cols, ptr(Et_dev), m_cols, 0.0, ptr(P_dev), m_cols)
+                ctx.call("pmd_gemm", 0, 1, Rc, rp, m_used, 1.0, ptr(right), m_cols, ptr(Et_dev), m_cols, 0.0, ptr(P_dev), m_cols)
             ldp = P_dev.shape[1]
             if Vp is None:
                 Vp = torch.empty((rp, T), dtype=torch.float32, device=ctx.device)
@@ -603,6 +645,7 @@ def localmd_decomposition(
             "tile_good": good_dev.cpu().numpy(), "tile_keep": keep_dev.cpu().numpy(), "tile_lambda": lam_dev.cpu().numpy(),
             "tile_ut": ut_dev.cpu().numpy(), "origins": origins, "pix": pix_c, "block_weights": block_weights,
             "max_components": r, "rank_before": R, "rank_after": rp, "timings": timings,
+            "orthogonalizer": ("cholesky" if (use_right and chol_ok) else "eigh"),
             "crop": crop, "dpad": dpad, "v_proj": Vp.cpu().numpy(),
         }
         return final_movie, diag

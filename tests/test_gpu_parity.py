@@ -339,3 +339,32 @@ def test_block_size_errors(gpu_ctx):
         localmd_amd.localmd_decomposition(mov[:, :9, :], (20, 20), 100, ctx=gpu_ctx)
     with pytest.raises(ValueError):
         localmd_amd.localmd_decomposition(mov, (20, 20), 100, temporal_avg_factor=200, ctx=gpu_ctx, sim_iters=2)
+
+
+def test_orthogonalizer_variants_agree(gpu_ctx):
+    """R > frames: the Cholesky form of P and the reference's eigenvector form give the same R, s, Vt
+    (they differ by an orthogonal factor absorbed by the projected SVD)."""
+    import localmd_amd
+    from localmd_amd import decomposition as Dm
+
+    Dm.QUIET = True
+    mov = _movie(300, 70, 80, seed=3)
+    outs = {}
+    for mode in ("eigh", "cholesky"):
+        np.random.seed(7)
+        outs[mode] = localmd_amd.localmd_decomposition(mov, (10, 10), 300, max_components=8, background_rank=3, sim_iters=10,
+                                                       seed=123, orthogonalizer=mode, return_diagnostics=True, ctx=gpu_ctx)
+    (a, da), (b, db) = outs["eigh"], outs["cholesky"]
+    assert da["orthogonalizer"] == "eigh" and db["orthogonalizer"] == "cholesky"
+    np.testing.assert_array_equal(da["tile_ranks"], db["tile_ranks"])
+    np.testing.assert_array_equal(a.u.indices, b.u.indices)
+    n = min(len(a.s), len(b.s))
+    strong = a.s[:n] > 5e-2 * a.s[0]
+    np.testing.assert_allclose(b.s[:n][strong], a.s[:n][strong], rtol=2e-3)
+    ura, urb = a.u @ a.r, b.u @ b.r
+    assert np.abs(urb.T @ urb - np.eye(urb.shape[1])).max() < 1e-2
+    rng = np.random.default_rng(0)
+    pi, pt = rng.integers(0, 5600, 400), rng.integers(0, 300, 400)
+    ra = np.einsum("pk,k,kp->p", ura[pi], a.s, a.v[:, pt])
+    rb = np.einsum("pk,k,kp->p", urb[pi], b.s, b.v[:, pt])
+    assert np.abs(ra - rb).max() < 2e-3 * np.abs(ra).max()
