@@ -13,6 +13,8 @@ two roughness cut-offs instead of simulating them), ``sim_iters``, ``return_diag
 "eigh" is the reference's eigendecomposition (decomposition.py:984-996); "cholesky" uses the
 Cholesky factor of the same Gram matrix (P differs by an orthogonal factor that the final SVD
 absorbs, so R, s, Vt are the same); "auto" (default) = cholesky with eigh as fallback.
+``distributed=True`` (one process per GPU, torch.distributed initialised): the tile grid is split
+over the ranks, per-tile results are gathered, every rank returns the same PMDArray.
 """
 import datetime
 import math
@@ -27,6 +29,7 @@ from scipy.sparse import coo_matrix
 from . import grid
 from ._lib import Context, ptr, PMDLibraryError, c_p, c_i, C
 from .pmdarray import PMDArray
+from .parallel import Dist, tile_partition
 
 STREAM_PRUNE = 5
 QUIET = False
@@ -252,6 +255,7 @@ def localmd_decomposition(
     thresholds=None,
     sim_iters: int = 250,
     orthogonalizer: str = "auto",
+    distributed: bool = False,
     return_diagnostics: bool = False,
     ctx: Optional[Context] = None,
 ):
@@ -412,12 +416,20 @@ def localmd_decomposition(
         keep_dev = torch.zeros((n_tiles, 64), dtype=torch.int32, device=ctx.device)
         ranks_dev = torch.zeros((n_tiles,), dtype=torch.int32, device=ctx.device)
         lam_dev = torch.zeros((n_tiles, 64), dtype=torch.float64, device=ctx.device)
-        ws = ctx.workspace(lib.pmd_tiles_workspace_bytes(n_tiles, b1, b2, P_pool, r, int(temporal_avg_factor), crop, ldv, D))
-        ctx.call("pmd_tiles_decompose", ptr(xf), ld_f, D, crop, ptr(pix_dev), n_tiles, b1, b2, ptr(pool_q_dev),
-                 pool_q.shape[1], P_pool, ptr(pool_idx_dev), ptr(pool_w_dev), r, int(temporal_avg_factor),
-                 float(np.float32(spatial_threshold)), float(np.float32(temporal_threshold)),
-                 int(max_consecutive_failures), seed, 0, 1, ptr(ut_dev), ptr(v_dev), ldv, ptr(stats_dev), ptr(good_dev),
-                 ptr(keep_dev), ptr(ranks_dev), ptr(lam_dev), ptr(ws), ws.numel())
+        dist = Dist(distributed)
+        runs = tile_partition(n_tiles, dist.world)
+        t_lo, t_hi = runs[dist.rank]
+        n_loc = t_hi - t_lo
+        if n_loc > 0:
+            ws = ctx.workspace(lib.pmd_tiles_workspace_bytes(n_loc, b1, b2, P_pool, r, int(temporal_avg_factor), crop, ldv, D))
+            ctx.call("pmd_tiles_decompose", ptr(xf), ld_f, D, crop, ptr(pix_dev[t_lo:]), n_loc, b1, b2, ptr(pool_q_dev),
+                     pool_q.shape[1], P_pool, ptr(pool_idx_dev), ptr(pool_w_dev), r, int(temporal_avg_factor),
+                     float(np.float32(spatial_threshold)), float(np.float32(temporal_threshold)),
+                     int(max_consecutive_failures), seed, t_lo, 1, ptr(ut_dev[t_lo:]), ptr(v_dev[t_lo:]), ldv,
+                     ptr(stats_dev[t_lo:]), ptr(good_dev[t_lo:]), ptr(keep_dev[t_lo:]), ptr(ranks_dev[t_lo:]),
+                     ptr(lam_dev[t_lo:]), ptr(ws), ws.numel())
+        for tns in (ut_dev, stats_dev, good_dev, keep_dev, ranks_dev, lam_dev):
+            dist.gather_runs(tns, runs)
         ctx.sync()
         lap("tiles", t0)
         _dbg("ut", ut_dev); _dbg("v_tiles", v_dev[:, :, :crop]); _dbg("tile_lambda", lam_dev)
@@ -486,7 +498,10 @@ def localmd_decomposition(
         # v_cropped = [tile traces ; background temporal basis] (decomposition.py:844, :932)
         m_cols = crop
         vc = torch.zeros((Rc, m_cols), dtype=torch.float32, device=ctx.device)
-        ctx.call("pmd_compact_rows", ptr(v_dev), ldv, ptr(col_off_dev), ptr(ranks_dev), crop, ptr(vc), m_cols, n_tiles)
+        if n_loc > 0:
+            ctx.call("pmd_compact_rows", ptr(v_dev[t_lo:]), ldv, ptr(col_off_dev[t_lo:]), ptr(ranks_dev[t_lo:]), crop, ptr(vc),
+                     m_cols, n_loc)
+        dist.gather_runs(vc, [(int(offsets[lo]), int(offsets[hi])) for lo, hi in runs])
         if K > 0:
             vc[Rt:Rt + K, :] = pj_dev[:, :crop]
         right = vc

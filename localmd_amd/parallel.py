@@ -1,0 +1,55 @@
+"""
+Multi-GPU plumbing: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI;
+"gloo" in the CPU tests).  Tiles are independent (decomposition.py:790-838), so the tile grid is
+split into contiguous runs of tiles (k-outer order, so a run is a band of tile rows) and every rank
+decomposes its run; the only exchange is the gather of the per-tile results before the global
+recombination.  The Gaussian test matrix of tile b is keyed by b (counter-based RNG), so the result
+does not depend on the number of ranks.
+"""
+from typing import List, Tuple
+
+
+def tile_partition(n_tiles: int, world: int) -> List[Tuple[int, int]]:
+    """Contiguous, balanced [lo, hi) runs of tiles, one per rank (earlier ranks get the remainder)."""
+    base, rem = divmod(int(n_tiles), int(world))
+    out, lo = [], 0
+    for r in range(world):
+        hi = lo + base + (1 if r < rem else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+class Dist:
+    """Thin view of the default process group (or a single-process stand-in)."""
+
+    def __init__(self, enabled: bool = False, group=None):
+        self.group = group
+        self.enabled = False
+        self.rank, self.world = 0, 1
+        if enabled:
+            import torch.distributed as dist
+
+            if not dist.is_initialized():
+                raise RuntimeError("distributed=True needs an initialised torch.distributed process group")
+            self.rank = dist.get_rank(group)
+            self.world = dist.get_world_size(group)
+            self.enabled = self.world > 1
+
+    def gather_runs(self, tensor, bounds):
+        """Every rank owns rows [bounds[r][0], bounds[r][1]) of ``tensor`` (dim 0) and has filled them;
+        after the call every rank holds all rows.  One broadcast per owner (runs may differ in length)."""
+        if not self.enabled:
+            return
+        import torch.distributed as dist
+
+        for r, (lo, hi) in enumerate(bounds):
+            if hi > lo:
+                dist.broadcast(tensor[lo:hi], src=dist.get_global_rank(self.group, r) if self.group is not None else r,
+                               group=self.group)
+
+    def barrier(self):
+        if self.enabled:
+            import torch.distributed as dist
+
+            dist.barrier(self.group)

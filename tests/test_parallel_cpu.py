@@ -1,0 +1,83 @@
+"""
+world_size-2 gloo test (CPU) of the multi-GPU plumbing: tile partition, gather of per-tile runs of
+unequal length, and independence of the result from the number of ranks.
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from localmd_amd.parallel import Dist, tile_partition
+
+
+def test_tile_partition_properties():
+    for n, w in [(2601, 8), (625, 2), (7, 8), (35, 4), (0, 3), (65025, 8)]:
+        runs = tile_partition(n, w)
+        assert len(runs) == w and runs[0][0] == 0 and runs[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(runs, runs[1:]))
+        sizes = [hi - lo for lo, hi in runs]
+        assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_tiles, out_dir):
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        d = Dist(True)
+        assert (d.rank, d.world, d.enabled) == (rank, world, True)
+        runs = tile_partition(n_tiles, world)
+        lo, hi = runs[rank]
+        # per-tile payloads: a "basis" block and a rank count that depend on the tile index only
+        ut = torch.zeros((n_tiles, 4, 6), dtype=torch.float32)
+        ranks = torch.zeros(n_tiles, dtype=torch.int32)
+        for t in range(lo, hi):
+            ut[t] = float(t + 1)
+            ranks[t] = (t % 3) + 1
+        d.gather_runs(ut, runs)
+        d.gather_runs(ranks, runs)
+        offsets = np.concatenate([[0], np.cumsum(ranks.numpy())])
+        # variable-length row blocks (the compacted temporal traces)
+        vc = torch.zeros((int(offsets[-1]), 5), dtype=torch.float32)
+        for t in range(lo, hi):
+            vc[offsets[t]:offsets[t + 1]] = float(t + 1)
+        d.gather_runs(vc, [(int(offsets[a]), int(offsets[b])) for a, b in runs])
+        d.barrier()
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), ut=ut.numpy(), ranks=ranks.numpy(), vc=vc.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_runs_world2_gloo(tmp_path):
+    import torch.multiprocessing as mp
+
+    n_tiles, world = 11, 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, n_tiles, str(tmp_path)), nprocs=world, join=True)
+    got = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    exp_ut = np.arange(1, n_tiles + 1, dtype=np.float32)[:, None, None] * np.ones((1, 4, 6), dtype=np.float32)
+    exp_ranks = (np.arange(n_tiles) % 3 + 1).astype(np.int32)
+    exp_vc = np.repeat(np.arange(1, n_tiles + 1, dtype=np.float32), exp_ranks)[:, None] * np.ones((1, 5), dtype=np.float32)
+    for g in got:
+        np.testing.assert_array_equal(g["ut"], exp_ut)
+        np.testing.assert_array_equal(g["ranks"], exp_ranks)
+        np.testing.assert_array_equal(g["vc"], exp_vc)
+
+
+def test_single_process_dist_is_a_noop():
+    d = Dist(False)
+    assert (d.rank, d.world, d.enabled) == (0, 1, False)
+    d.gather_runs(None, [(0, 1)])
+    d.barrier()
+    with pytest.raises(RuntimeError):
+        Dist(True)
