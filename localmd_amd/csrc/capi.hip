@@ -170,6 +170,22 @@ int pmd_tiles_decompose(pmd_ctx* ctx, const float* xf, long ldx, long n_rows, in
                                   V_out, ldv, stats_out, good_out, keep_out, ranks_out, lam_out, ws, ws_bytes);
 }
 
+size_t pmd_tiles_residual_workspace_bytes(int n_tiles, int b1, int b2, int r, int a, int L, long n_rows) {
+  return pmd_tiles_residual_workspace_bytes_impl(n_tiles, b1 * b2, r, a, L, n_rows);
+}
+int pmd_tiles_residual(pmd_ctx* ctx, const float* xw, long ldx, long n_rows, int L, const int* tile_pix, int n_tiles,
+                       int b1, int b2, int r, int a, float thr_s, float thr_t, int max_fail, uint64_t seed,
+                       uint32_t omega_index0, uint32_t omega_index_step, float* Ucur, int* counts, float* stats_out,
+                       int* good_out, int* keep_out, void* ws, size_t ws_bytes) {
+  CTX_CHECK(ctx);
+  return pmd_tiles_residual_impl(ctx, xw, ldx, n_rows, L, tile_pix, n_tiles, b1, b2, r, a, thr_s, thr_t, max_fail, seed,
+                                 omega_index0, omega_index_step, Ucur, counts, stats_out, good_out, keep_out, ws, ws_bytes);
+}
+int pmd_tiles_truncate(pmd_ctx* ctx, float* U, int dpad, const int* counts, int n_tiles) {
+  CTX_CHECK(ctx);
+  return pmd_launch_tile_truncate(ctx, U, dpad, counts, n_tiles);
+}
+
 int pmd_weight_tiles(pmd_ctx* ctx, const float* Ut, int dpad, const int* tile_pix, int d, const float* w,
                      const float* cumw, const int* ranks, float* Uw_out, int n_tiles) {
   CTX_CHECK(ctx);

@@ -135,6 +135,96 @@ int pmd_tiles_decompose_impl(pmd_ctx* ctx, const float* Xf, long ldx, long n_row
 }
 
 // ------------------------------------------------------------------------------------------
+// residual window (decomposition.py:333-387 single_residual_block_md + :501-515): components of the
+// part of the window that the current basis E does not explain.  (I - E E^T) commutes with the
+// temporal bin average, so the residual is never materialised at full resolution.
+// ------------------------------------------------------------------------------------------
+struct resid_plan {
+  int nb, l, dpad, nref;
+  long ld_b, ld_L;
+  float *xbar, *wbar, *ar, *omT, *yt, *qt, *bm, *unew, *tmp, *util, *vmat;
+  double *gpart, *nmat, *lam;
+  size_t zero_bytes;
+};
+
+static int plan_resid(pmd_arena& ar, resid_plan& p, int n, int d, int r, int a, int L, long n_rows) {
+  p.nb = L / a;
+  p.l = r + 10;
+  p.dpad = pmd_tile_dpad(d);
+  if (p.dpad < 0) return PMD_ERR_UNSUPPORTED;
+  p.nref = d < p.l ? d : p.l;
+  p.ld_b = pmd_time_ld(p.nb);
+  p.ld_L = pmd_time_ld(L);
+  p.omT = ar.take_n<float>((size_t)n * 64 * p.ld_b);
+  p.ar = ar.take_n<float>((size_t)n * d * p.ld_b);
+  p.yt = ar.take_n<float>((size_t)n * 64 * p.dpad);
+  p.qt = ar.take_n<float>((size_t)n * 64 * p.dpad);
+  p.unew = ar.take_n<float>((size_t)n * 64 * p.dpad);
+  p.tmp = ar.take_n<float>((size_t)n * 64 * p.dpad);
+  p.util = ar.take_n<float>((size_t)n * 64 * p.dpad);
+  p.zero_bytes = ar.used;
+  p.xbar = ar.take_n<float>((size_t)n_rows * p.ld_b);
+  p.wbar = ar.take_n<float>((size_t)n * 64 * p.ld_b);
+  p.bm = ar.take_n<float>((size_t)n * 64 * p.ld_b);
+  p.vmat = ar.take_n<float>((size_t)n * 64 * p.ld_L);
+  p.gpart = ar.take_n<double>((size_t)n * GRAM_SLICES * 4096);
+  p.nmat = ar.take_n<double>((size_t)n * 4096);
+  p.lam = ar.take_n<double>((size_t)n * 64);
+  return PMD_OK;
+}
+
+size_t pmd_tiles_residual_workspace_bytes_impl(int n, int d, int r, int a, int L, long n_rows) {
+  pmd_arena ar((void*)0x1000, ~size_t(0) >> 1);
+  resid_plan p;
+  if (plan_resid(ar, p, n, d, r, a, L, n_rows) != PMD_OK) return 0;
+  return ar.used + 4096;
+}
+
+int pmd_tiles_residual_impl(pmd_ctx* ctx, const float* Xw, long ldx, long n_rows, int L, const int* tile_pix, int n,
+                            int b1, int b2, int r, int a, float thr_s, float thr_t, int max_fail, uint64_t seed,
+                            uint32_t omega_index0, uint32_t omega_index_step, float* Ucur, int* counts, float* stats_out,
+                            int* good_out, int* keep_out, void* ws, size_t ws_bytes) {
+  const int d = b1 * b2;
+  if (r < 1 || r + 10 > 64) return pmd_fail(ctx, PMD_ERR_UNSUPPORTED, "pmd_tiles_residual", "max_components must be in [1, 54]");
+  if (a < 1 || L % a != 0 || L / a < 1) return pmd_fail(ctx, PMD_ERR_ARG, "pmd_tiles_residual", "window length must be a positive multiple of temporal_avg_factor");
+  if (r > L / a) return pmd_fail(ctx, PMD_ERR_ARG, "pmd_tiles_residual", "max_components exceeds window frames/temporal_avg_factor");
+  if (ldx < pmd_time_ld(L)) return pmd_fail(ctx, PMD_ERR_ARG, "pmd_tiles_residual", "leading dimension too small");
+  pmd_arena ar(ws, ws_bytes);
+  resid_plan p;
+  if (plan_resid(ar, p, n, d, r, a, L, n_rows) != PMD_OK) return pmd_fail(ctx, PMD_ERR_UNSUPPORTED, "pmd_tiles_residual", "tile too large");
+  if (ar.overflow) return pmd_fail(ctx, PMD_ERR_WORKSPACE, "pmd_tiles_residual", "workspace too small");
+  const long s64d = 64L * p.dpad, s64b = 64L * p.ld_b, s64L = 64L * p.ld_L;
+  PMD_HIP(ctx, hipMemsetAsync(ws, 0, p.zero_bytes, ctx->stream));
+
+  // A_r = (I - E E^T) binavg(X_window)
+  RUN(pmd_launch_bin_average(ctx, Xw, ldx, n_rows, a, p.nb, p.xbar, p.ld_b));
+  RUN(pmd_launch_tile_atx(ctx, p.xbar, p.ld_b, tile_pix, d, 0, d, Ucur, s64d, p.dpad, p.wbar, s64b, p.ld_b, n, p.nb, 1));
+  RUN(pmd_launch_tile_residual_rows(ctx, p.xbar, p.ld_b, tile_pix, d, Ucur, p.dpad, p.wbar, p.ld_b, r, p.nb, p.ar, p.ld_b, n));
+  // rSVD of A_r (decomposition.py:378, :59-73)
+  for (int t0 = 0; t0 < n; t0 += 32768) {
+    const int tn = (n - t0 < 32768) ? n - t0 : 32768;
+    RUN(pmd_launch_rng(ctx, seed, PMD_STREAM_TILE_OMEGA, omega_index0 + (uint32_t)t0 * omega_index_step, omega_index_step, tn,
+                       p.nb, p.l, 1, p.omT + (long)t0 * s64b, p.ld_b, s64b));
+  }
+  RUN(pmd_launch_tile_xbt(ctx, p.ar, p.ld_b, nullptr, 0, d, d, p.omT, s64b, p.ld_b, p.yt, s64d, 0, p.dpad, n, p.nb, 1));
+  RUN(pmd_launch_small_qr(ctx, p.yt, s64d, p.dpad, d, p.l, p.qt, s64d, p.dpad, n));
+  RUN(pmd_launch_tile_atx(ctx, p.ar, p.ld_b, nullptr, 0, d, d, p.qt, s64d, p.dpad, p.bm, s64b, p.ld_b, n, p.nb, 1));
+  RUN(pmd_launch_tile_gram(ctx, p.bm, s64b, p.ld_b, p.nb, n, 1, p.gpart));
+  RUN(pmd_launch_small_eig(ctx, p.gpart, 1, p.nref, 0, 0.0, p.nmat, p.lam, n));
+  RUN(pmd_launch_tile_rowmix(ctx, p.qt, s64d, p.dpad, p.nmat, 4096, p.nref, r, p.unew, s64d, p.dpad, d, n));
+  // v = u^T (I - E E^T) X = utilde^T X with utilde = u - E (E^T u)   (decomposition.py:370-371, :379)
+  RUN(pmd_launch_tile_cross_gram(ctx, Ucur, p.unew, s64d, p.dpad, d, p.nmat, n));
+  RUN(pmd_launch_tile_rowmix(ctx, Ucur, s64d, p.dpad, p.nmat, 4096, r, r, p.tmp, s64d, p.dpad, d, n));
+  PMD_HIP(ctx, hipMemcpyAsync(p.util, p.unew, (size_t)n * s64d * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+  RUN(pmd_launch_tile_sub(ctx, p.util, p.tmp, s64d, p.dpad, d, n));
+  RUN(pmd_launch_tile_atx(ctx, Xw, ldx, tile_pix, d, 0, d, p.util, s64d, p.dpad, p.vmat, s64L, p.ld_L, n, L, 2));
+  // fitness, keep/discard scan, append behind the existing components
+  RUN(pmd_launch_stats_roughness(ctx, p.unew, s64d, p.dpad, b1, b2, p.vmat, s64L, p.ld_L, L, r, stats_out, n));
+  RUN(pmd_launch_tile_append(ctx, stats_out, r, thr_s, thr_t, max_fail, r, p.unew, Ucur, p.dpad, counts, good_out, keep_out, n));
+  return PMD_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // threshold simulation (decomposition.py:76-131, :147-181): rank-1 rSVD of N(0,1) tiles
 // ------------------------------------------------------------------------------------------
 static const int SIM_BATCH = 50;

@@ -111,3 +111,20 @@ int pmd_projected_svd_factored_impl(pmd_ctx* ctx, const float* M, int Rc, int m,
                                     float* Vt_out, long ldvt, float* Vp_out, long ldvp, void* ws, size_t ws_bytes);
 int pmd_orthogonalize_chol_impl(pmd_ctx* ctx, const float* M, int Rc, int m, long ldm, const float* GM, long ldgm,
                                 float* Et_out, long lde, int* ok_host, void* ws, size_t ws_bytes);
+
+// residual windows (single_residual_block_md)
+int pmd_launch_bin_average(pmd_ctx* ctx, const float* X, long ldx, long n_rows, int a, int nbins, float* xbar, long ldb);
+int pmd_launch_tile_cross_gram(pmd_ctx* ctx, const float* A, const float* B, long tile_stride, int ld, int len,
+                               double* G, int n_tiles);
+int pmd_launch_tile_residual_rows(pmd_ctx* ctx, const float* X, long ldx, const int* pix, int d, const float* E,
+                                  int e_ld, const float* W, long w_ld, int r, int len, float* out, long out_ld,
+                                  int n_tiles);
+int pmd_launch_tile_sub(pmd_ctx* ctx, float* a, const float* b, long tile_stride, int ld, int len, int n_tiles);
+int pmd_launch_tile_append(pmd_ctx* ctx, const float* stats, int r, float thr_s, float thr_t, int max_fail, int cap,
+                           const float* Unew, float* Ucur, int ld, int* counts, int* good, int* keep, int n_tiles);
+int pmd_launch_tile_truncate(pmd_ctx* ctx, float* U, int ld, const int* counts, int n_tiles);
+size_t pmd_tiles_residual_workspace_bytes_impl(int n, int d, int r, int a, int L, long n_rows);
+int pmd_tiles_residual_impl(pmd_ctx* ctx, const float* Xw, long ldx, long n_rows, int L, const int* tile_pix, int n,
+                            int b1, int b2, int r, int a, float thr_s, float thr_t, int max_fail, uint64_t seed,
+                            uint32_t omega_index0, uint32_t omega_index_step, float* Ucur, int* counts, float* stats_out,
+                            int* good_out, int* keep_out, void* ws, size_t ws_bytes);

@@ -303,6 +303,18 @@ __global__ __launch_bounds__(256) void tile_pool_kernel(const float* __restrict_
   }
 }
 
+int pmd_launch_bin_average(pmd_ctx* ctx, const float* X, long ldx, long n_rows, int a, int nbins, float* xbar, long ldb) {
+  int bx = (nbins + 255) / 256;
+  if (bx > 8) bx = 8;
+  for (long c0 = 0; c0 < n_rows; c0 += 32768) {
+    const long cn = (n_rows - c0 < 32768) ? n_rows - c0 : 32768;
+    hipLaunchKernelGGL(bin_average_kernel, dim3(bx, (unsigned)cn), dim3(256), 0, ctx->stream, X + c0 * ldx, ldx, a, nbins,
+                       xbar + c0 * ldb, ldb);
+    PMD_LAUNCH_CHECK(ctx, "bin_average_kernel");
+  }
+  return PMD_OK;
+}
+
 // xbar: n_rows x ld_ab scratch (n_rows = pixel rows of X)
 int pmd_launch_tile_pool_bin(pmd_ctx* ctx, const float* X, long ldx, long n_rows, const int* pix, int n_tiles, int d,
                              const int* pool_q, int pool_max, int P, int a, int nbins, float* xbar, float* abar,

@@ -394,3 +394,176 @@ int pmd_launch_decide(pmd_ctx* ctx, const float* stats, int r, float thr_s, floa
   PMD_LAUNCH_CHECK(ctx, "decide_kernel");
   return PMD_OK;
 }
+
+// ---------------------------------------------------------------- residual-window helpers --
+// (single_residual_block_md, decomposition.py:364-387)
+
+// cross Gram of two [comp][x] arrays: Gx[tile][c][c'] = sum_x A[tile][c][x] * B[tile][c'][x]  (fp64)
+__global__ __launch_bounds__(256) void tile_cross_gram_kernel(const float* __restrict__ A, const float* __restrict__ B,
+                                                              long tile_stride, int ld, int len,
+                                                              double* __restrict__ G) {
+  __shared__ float sa[64][33];
+  __shared__ float sb[64][33];
+  const int tile = blockIdx.x;
+  const int ti = threadIdx.x >> 4, tj = threadIdx.x & 15;
+  const float* a = A + (long)tile * tile_stride;
+  const float* b = B + (long)tile * tile_stride;
+  double acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+  for (int x0 = 0; x0 < len; x0 += 32) {
+    for (int i = threadIdx.x; i < 64 * 32; i += 256) {
+      const int r = i >> 5, cx = i & 31;
+      const bool in = x0 + cx < len;
+      sa[r][cx] = in ? a[(long)r * ld + x0 + cx] : 0.f;
+      sb[r][cx] = in ? b[(long)r * ld + x0 + cx] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int cx = 0; cx < 32; ++cx) {
+      double av[4], bv[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { av[i] = (double)sa[4 * ti + i][cx]; bv[i] = (double)sb[4 * tj + i][cx]; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fma(av[i], bv[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+  double* g = G + (long)tile * 4096;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) g[(4 * ti + i) * 64 + 4 * tj + j] = acc[i][j];
+}
+
+int pmd_launch_tile_cross_gram(pmd_ctx* ctx, const float* A, const float* B, long tile_stride, int ld, int len,
+                               double* G, int n_tiles) {
+  pmd_prof_scope prof__(ctx, "tile_cross_gram");
+  if (n_tiles <= 0) return PMD_OK;
+  hipLaunchKernelGGL(tile_cross_gram_kernel, dim3(n_tiles), dim3(256), 0, ctx->stream, A, B, tile_stride, ld, len, G);
+  PMD_LAUNCH_CHECK(ctx, "tile_cross_gram_kernel");
+  return PMD_OK;
+}
+
+// out[tile][q][x] = X[pix[tile][q]][x] - sum_{c<r} E[tile][c][q] * W[tile][c][x]      (x < len)
+__global__ __launch_bounds__(256) void tile_residual_rows_kernel(const float* __restrict__ X, long ldx,
+                                                                 const int* __restrict__ pix, int d,
+                                                                 const float* __restrict__ E, int e_ld,
+                                                                 const float* __restrict__ W, long w_ld, int r, int len,
+                                                                 float* __restrict__ out, long out_ld) {
+  const int tile = blockIdx.z, q = blockIdx.y;
+  const float* e = E + (long)tile * 64 * e_ld + q;
+  const float* w = W + (long)tile * 64 * w_ld;
+  const float* xr = X + (long)pix[(long)tile * d + q] * ldx;
+  for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < len; x += gridDim.x * blockDim.x) {
+    float acc = 0.f;
+    for (int c = 0; c < r; ++c) acc = fmaf(e[(long)c * e_ld], w[(long)c * w_ld + x], acc);
+    out[((long)tile * d + q) * out_ld + x] = xr[x] - acc;
+  }
+}
+
+int pmd_launch_tile_residual_rows(pmd_ctx* ctx, const float* X, long ldx, const int* pix, int d, const float* E,
+                                  int e_ld, const float* W, long w_ld, int r, int len, float* out, long out_ld,
+                                  int n_tiles) {
+  pmd_prof_scope prof__(ctx, "tile_residual_rows");
+  if (n_tiles <= 0) return PMD_OK;
+  int bx = (len + 255) / 256;
+  if (bx > 4) bx = 4;
+  for (int t0 = 0; t0 < n_tiles; t0 += 32768) {
+    const int tn = (n_tiles - t0 < 32768) ? n_tiles - t0 : 32768;
+    hipLaunchKernelGGL(tile_residual_rows_kernel, dim3(bx, d, tn), dim3(256), 0, ctx->stream, X, ldx, pix + (long)t0 * d, d,
+                       E + (long)t0 * 64 * e_ld, e_ld, W + (long)t0 * 64 * w_ld, w_ld, r, len,
+                       out + (long)t0 * d * out_ld, out_ld);
+    PMD_LAUNCH_CHECK(ctx, "tile_residual_rows_kernel");
+  }
+  return PMD_OK;
+}
+
+// a[tile][c][x] -= b[tile][c][x]   (c < 64, x < len)
+__global__ void tile_sub_kernel(float* __restrict__ a, const float* __restrict__ b, long tile_stride, int ld, int len) {
+  const int tile = blockIdx.y;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 64 * len; i += gridDim.x * blockDim.x) {
+    const int c = i / len, x = i - c * len;
+    a[(long)tile * tile_stride + (long)c * ld + x] -= b[(long)tile * tile_stride + (long)c * ld + x];
+  }
+}
+
+int pmd_launch_tile_sub(pmd_ctx* ctx, float* a, const float* b, long tile_stride, int ld, int len, int n_tiles) {
+  for (int t0 = 0; t0 < n_tiles; t0 += 32768) {
+    const int tn = (n_tiles - t0 < 32768) ? n_tiles - t0 : 32768;
+    hipLaunchKernelGGL(tile_sub_kernel, dim3(16, tn), dim3(256), 0, ctx->stream, a + (long)t0 * tile_stride,
+                       b + (long)t0 * tile_stride, tile_stride, ld, len);
+    PMD_LAUNCH_CHECK(ctx, "tile_sub_kernel");
+  }
+  return PMD_OK;
+}
+
+// decisions of a residual window + append (decomposition.py:501-515): the kept prefix of Unew (capped by
+// the remaining capacity) is copied behind the counts[tile] components already in Ucur.
+__global__ __launch_bounds__(256) void tile_append_kernel(const float* __restrict__ stats, int r, float thr_s,
+                                                          float thr_t, int max_fail, int cap,
+                                                          const float* __restrict__ Unew, float* __restrict__ Ucur,
+                                                          int ld, int* __restrict__ counts, int* __restrict__ good,
+                                                          int* __restrict__ keep) {
+  __shared__ int s_take, s_base;
+  const int tile = blockIdx.x;
+  if (threadIdx.x == 0) {
+    int fails = 0, kept = 0;
+    bool all_fails = false;
+    for (int c = 0; c < PMD_RPAD; ++c) {
+      int g = 0, k = 0;
+      if (c < r) {
+        const float sp = stats[((long)tile * PMD_RPAD + c) * 2 + 0];
+        const float tp = stats[((long)tile * PMD_RPAD + c) * 2 + 1];
+        g = (sp < thr_s) && (tp < thr_t);
+        if (all_fails) k = 0;
+        else if (!g) { fails++; k = 1; if (fails == max_fail) all_fails = true; }
+        else { fails = 0; k = 1; }
+        kept += k;
+      }
+      good[(long)tile * PMD_RPAD + c] = g;
+      keep[(long)tile * PMD_RPAD + c] = k;
+    }
+    const int base = counts[tile];
+    const int remaining = cap - base;
+    s_take = kept < remaining ? kept : remaining;
+    s_base = base;
+    counts[tile] = base + s_take;
+  }
+  __syncthreads();
+  const int take = s_take, base = s_base;
+  for (int i = threadIdx.x; i < take * ld; i += 256) {
+    const int c = i / ld, x = i - c * ld;
+    Ucur[(long)tile * 64 * ld + (long)(base + c) * ld + x] = Unew[(long)tile * 64 * ld + (long)c * ld + x];
+  }
+}
+
+int pmd_launch_tile_append(pmd_ctx* ctx, const float* stats, int r, float thr_s, float thr_t, int max_fail, int cap,
+                           const float* Unew, float* Ucur, int ld, int* counts, int* good, int* keep, int n_tiles) {
+  if (n_tiles <= 0) return PMD_OK;
+  hipLaunchKernelGGL(tile_append_kernel, dim3(n_tiles), dim3(256), 0, ctx->stream, stats, r, thr_s, thr_t, max_fail, cap,
+                     Unew, Ucur, ld, counts, good, keep);
+  PMD_LAUNCH_CHECK(ctx, "tile_append_kernel");
+  return PMD_OK;
+}
+
+// rows c >= counts[tile] of U[tile][c][:] are cleared (components that were not kept)
+__global__ void tile_truncate_kernel(float* __restrict__ U, int ld, const int* __restrict__ counts) {
+  const int tile = blockIdx.y;
+  const int k = counts[tile];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < (PMD_RPAD - k) * ld; i += gridDim.x * blockDim.x)
+    U[(long)tile * 64 * ld + (long)k * ld + i] = 0.f;
+}
+
+int pmd_launch_tile_truncate(pmd_ctx* ctx, float* U, int ld, const int* counts, int n_tiles) {
+  for (int t0 = 0; t0 < n_tiles; t0 += 32768) {
+    const int tn = (n_tiles - t0 < 32768) ? n_tiles - t0 : 32768;
+    hipLaunchKernelGGL(tile_truncate_kernel, dim3(16, tn), dim3(256), 0, ctx->stream, U + (long)t0 * 64 * ld, ld, counts + t0);
+    PMD_LAUNCH_CHECK(ctx, "tile_truncate_kernel");
+  }
+  return PMD_OK;
+}

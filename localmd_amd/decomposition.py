@@ -390,10 +390,14 @@ def localmd_decomposition(
                 "To avoid this, initialize with more frames or reduce temporal avg factor")
             max_components = int(Tf // temporal_avg_factor)
         crop = (Tf // temporal_avg_factor) * temporal_avg_factor
-        if min(window_chunks, crop) < crop:
-            raise NotImplementedError(
-                "window_chunks < frame_range (multi-window residual fitting, decomposition.py:333-387) is not "
-                "available in the HIP pipeline yet")
+        # temporal windows of windowed_pmd (decomposition.py:455-463)
+        win_len = int(min(window_chunks, crop))
+        win_starts = list(range(0, crop, win_len))
+        if win_starts[-1] + win_len > crop:
+            win_starts[-1] = crop - win_len
+        n_win = len(win_starts)
+        if n_win > 1 and win_len % temporal_avg_factor != 0:
+            raise ValueError("window_chunks must be a multiple of temporal_avg_factor")
         pix_c, origins = grid.tile_pixel_lists((d1, d2), block_sizes, dim_1_iters, dim_2_iters)
         n_tiles = pix_c.shape[0]
         pool_q, pool_idx, pool_w, pooled_shape = grid.pooling_maps(block_sizes, int(spatial_avg_factor))
@@ -420,14 +424,43 @@ def localmd_decomposition(
         runs = tile_partition(n_tiles, dist.world)
         t_lo, t_hi = runs[dist.rank]
         n_loc = t_hi - t_lo
-        if n_loc > 0:
-            ws = ctx.workspace(lib.pmd_tiles_workspace_bytes(n_loc, b1, b2, P_pool, r, int(temporal_avg_factor), crop, ldv, D))
+        thr_s32, thr_t32 = float(np.float32(spatial_threshold)), float(np.float32(temporal_threshold))
+        a_f = int(temporal_avg_factor)
+        if n_loc > 0 and n_win == 1:
+            ws = ctx.workspace(lib.pmd_tiles_workspace_bytes(n_loc, b1, b2, P_pool, r, a_f, crop, ldv, D))
             ctx.call("pmd_tiles_decompose", ptr(xf), ld_f, D, crop, ptr(pix_dev[t_lo:]), n_loc, b1, b2, ptr(pool_q_dev),
-                     pool_q.shape[1], P_pool, ptr(pool_idx_dev), ptr(pool_w_dev), r, int(temporal_avg_factor),
-                     float(np.float32(spatial_threshold)), float(np.float32(temporal_threshold)),
+                     pool_q.shape[1], P_pool, ptr(pool_idx_dev), ptr(pool_w_dev), r, a_f, thr_s32, thr_t32,
                      int(max_consecutive_failures), seed, t_lo, 1, ptr(ut_dev[t_lo:]), ptr(v_dev[t_lo:]), ldv,
                      ptr(stats_dev[t_lo:]), ptr(good_dev[t_lo:]), ptr(keep_dev[t_lo:]), ptr(ranks_dev[t_lo:]),
                      ptr(lam_dev[t_lo:]), ptr(ws), ws.numel())
+        elif n_loc > 0:
+            # several windows: first window = single_block_md, later ones fit the residual (decomposition.py:471-515);
+            # the Gaussian matrix of (tile, window) is logical array tile * n_win + window
+            ld_w = lib.pmd_time_ld(win_len)
+            xw = torch.zeros((movie.rows_alloc, ld_w), dtype=torch.float32, device=ctx.device)
+            vw = torch.empty((n_loc, 64, ld_w), dtype=torch.float32, device=ctx.device)
+            st_w = torch.zeros((n_loc, 64, 2), dtype=torch.float32, device=ctx.device)
+            gd_w = torch.zeros((n_loc, 64), dtype=torch.int32, device=ctx.device)
+            kp_w = torch.zeros((n_loc, 64), dtype=torch.int32, device=ctx.device)
+            for widx, w0 in enumerate(win_starts):
+                xw[:D, :win_len] = xf[:D, w0:w0 + win_len]
+                if widx == 0:
+                    ws = ctx.workspace(lib.pmd_tiles_workspace_bytes(n_loc, b1, b2, P_pool, r, a_f, win_len, ld_w, D))
+                    ctx.call("pmd_tiles_decompose", ptr(xw), ld_w, D, win_len, ptr(pix_dev[t_lo:]), n_loc, b1, b2,
+                             ptr(pool_q_dev), pool_q.shape[1], P_pool, ptr(pool_idx_dev), ptr(pool_w_dev), r, a_f, thr_s32,
+                             thr_t32, int(max_consecutive_failures), seed, t_lo * n_win, n_win, ptr(ut_dev[t_lo:]), ptr(vw),
+                             ld_w, ptr(stats_dev[t_lo:]), ptr(good_dev[t_lo:]), ptr(keep_dev[t_lo:]), ptr(ranks_dev[t_lo:]),
+                             ptr(lam_dev[t_lo:]), ptr(ws), ws.numel())
+                    ctx.call("pmd_tiles_truncate", ptr(ut_dev[t_lo:]), dpad, ptr(ranks_dev[t_lo:]), n_loc)
+                else:
+                    ws = ctx.workspace(lib.pmd_tiles_residual_workspace_bytes(n_loc, b1, b2, r, a_f, win_len, D))
+                    ctx.call("pmd_tiles_residual", ptr(xw), ld_w, D, win_len, ptr(pix_dev[t_lo:]), n_loc, b1, b2, r, a_f,
+                             thr_s32, thr_t32, int(max_consecutive_failures), seed, t_lo * n_win + widx, n_win,
+                             ptr(ut_dev[t_lo:]), ptr(ranks_dev[t_lo:]), ptr(st_w), ptr(gd_w), ptr(kp_w), ptr(ws), ws.numel())
+            del xw, vw
+            # temporal traces over all fitted frames: U_b^T X (get_temporal_projector, decomposition.py:518-523)
+            ctx.call("pmd_tiles_project", ptr(xf), ld_f, crop, ptr(pix_dev[t_lo:]), n_loc, d, ptr(ut_dev[t_lo:]), dpad,
+                     ptr(v_dev[t_lo:]), ldv, 2)
         for tns in (ut_dev, stats_dev, good_dev, keep_dev, ranks_dev, lam_dev):
             dist.gather_runs(tns, runs)
         ctx.sync()

@@ -368,3 +368,16 @@ def test_orthogonalizer_variants_agree(gpu_ctx):
     ra = np.einsum("pk,k,kp->p", ura[pi], a.s, a.v[:, pt])
     rb = np.einsum("pk,k,kp->p", urb[pi], b.s, b.v[:, pt])
     assert np.abs(ra - rb).max() < 2e-3 * np.abs(ra).max()
+
+
+def test_full_pipeline_multi_window_residual(gpu_ctx):
+    """window_chunks < frame_range: first window single_block_md, later windows fit the residual
+    (decomposition.py:333-387, :471-515)."""
+    mov = _movie(900, 40, 44, seed=6)
+    pmd, diag, ref = _compare_full(gpu_ctx, mov, (20, 20), 600, max_components=8, background_rank=2, sim_iters=10,
+                                   window_chunks=200)
+    assert len(diag["frames"]) == 600
+    exact, knife = _check_full(pmd, diag, ref, mov, vt_tol=3e-3)
+    # the later windows must have contributed components in at least one tile
+    first = np.array([d[0]["kept"].sum() for d in ref.diag["tile_diag"]])
+    assert np.any(ref.diag["tile_ranks"] > first)
