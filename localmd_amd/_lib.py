@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpmd_hip.so")
+LIB_PATH = os.environ.get("PMD_HIP_LIB") or os.path.join(_HERE, "libpmd_hip.so")
 
 c_i, c_l, c_f, c_d, c_p = C.c_int, C.c_long, C.c_float, C.c_double, C.c_void_p
 c_u64, c_u32, c_sz = C.c_uint64, C.c_uint32, C.c_size_t

@@ -23,8 +23,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // lane slot kk <-> row q = 16*J + 4*kk + s, so one float4 of A feeds four MFMAs and the LDS
 // rows of one 32-lane group sit 4 rows = 16 banks apart (row stride TC+4 floats): conflict-free.
 // ------------------------------------------------------------------------------------------
-template <int KJW, int KS>
-__global__ __launch_bounds__(256 * KS) void tile_atx_kernel(const float* __restrict__ X, long ldx,
+template <int KJW, int KS, int NS>
+__global__ __launch_bounds__(256 * KS * NS) void tile_atx_kernel(const float* __restrict__ X, long ldx,
                                                             const int* __restrict__ pix, int pix_stride,
                                                             long row0_stride, int d,
                                                             const float* __restrict__ A, long a_tile_stride, int a_ld,
@@ -34,16 +34,22 @@ __global__ __launch_bounds__(256 * KS) void tile_atx_kernel(const float* __restr
   constexpr int TC = 16 * NTW;
   constexpr int LSTR = TC + 4;
   constexpr int DPAD = 16 * KJW * KS;
-  constexpr int NTHREADS = 256 * KS;
+  // NS = 2: a second group of four waves takes the second 16-frame N tile, so every SIMD hosts two
+  // waves whose LDS refills, barriers and stores overlap with the other one's MFMAs.
+  static_assert(NS == 1 || KS == 1, "the N split is only built for KS = 1");
+  constexpr int NTHREADS = 256 * KS * NS;
   constexpr int QUADS = TC / 4;
   constexpr int NPRE = (DPAD * QUADS + NTHREADS - 1) / NTHREADS;
+  // two LDS buffers (one barrier per chunk) whenever they fit next to the K-split scratch
+  constexpr bool DB = (2 * DPAD * LSTR + (KS - 1) * 2048 + 4) * 4 <= 160 * 1024;
+  constexpr int NBUF = DB ? 2 : 1;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  float* xs = lds;
-  float* red = lds + DPAD * LSTR;
+  float* red = lds + NBUF * DPAD * LSTR;
+  constexpr int TRASH = NBUF * DPAD * LSTR + (KS - 1) * 2048;  // 16-byte slot nobody reads
 
   const int tile = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int mt = wid & 3, ks = wid >> 2;
+  const int mt = wid & 3, ks = (NS == 1) ? (wid >> 2) : 0, nh = (NS == 1) ? 0 : (wid >> 2);
   const int n16 = lane & 15, kk = lane >> 4;
   const int kz = blockIdx.z;           // grid-level K split (d > DPAD)
   const int qbase = kz * DPAD;
@@ -68,47 +74,86 @@ __global__ __launch_bounds__(256 * KS) void tile_atx_kernel(const float* __restr
   for (int k = 0; k < NPRE; ++k) {
     const int i = tid + k * NTHREADS;
     const int q = i / QUADS, j = i - q * QUADS;
-    if (q < dloc) {
-      const long row = pix ? (long)pix[(long)tile * pix_stride + qbase + q] : (long)tile * row0_stride + qbase + q;
-      goff[k] = row * ldx + 4 * j;
-      loff[k] = q * LSTR + 4 * j;
-    } else {
-      goff[k] = -1;
-      loff[k] = 0;
-    }
+    // branch-free: an item beyond the tile reads the tile's first row and lands in a trash slot
+    const int qc = (q < dloc) ? q : 0;
+    const long row = pix ? (long)pix[(long)tile * pix_stride + qbase + qc] : (long)tile * row0_stride + qbase + qc;
+    goff[k] = row * ldx + 4 * j;
+    loff[k] = (q < dloc) ? q * LSTR + 4 * j : TRASH;
   }
-  for (int i = tid; i < DPAD * LSTR; i += NTHREADS) xs[i] = 0.f;
+  for (int i = tid; i < NBUF * DPAD * LSTR; i += NTHREADS) lds[i] = 0.f;
   __syncthreads();
 
   f32x4 pre[NPRE];
 #pragma unroll
-  for (int k = 0; k < NPRE; ++k)
-    if (goff[k] >= 0) pre[k] = *reinterpret_cast<const f32x4*>(X + goff[k] + (long)c_begin * TC);
+  for (int k = 0; k < NPRE; ++k) pre[k] = *reinterpret_cast<const f32x4*>(X + goff[k] + (long)c_begin * TC);
+#pragma unroll
+  for (int k = 0; k < NPRE; ++k) *reinterpret_cast<f32x4*>(lds + (loff[k] == TRASH ? TRASH : loff[k])) = pre[k];
+  __syncthreads();
 
-  float* outp = Out + (long)tile * out_tile_stride + (long)(16 * mt + 4 * kk) * ldo + n16;
-  const float* xrd = xs + (ks * 16 * KJW + 4 * kk) * LSTR + n16;
+  float* outp = Out + (long)tile * out_tile_stride + (long)(16 * mt + 4 * kk) * ldo + n16 + 16 * nh;
+  const int rd_off = (ks * 16 * KJW + 4 * kk) * LSTR + n16 + 16 * nh;
 
   for (int c = c_begin; c < c_end; ++c) {
+    const int cur = DB ? ((c - c_begin) & 1) : 0;
+    const float* xrd = lds + cur * (DPAD * LSTR) + rd_off;
+    const bool more = c + 1 < c_end;
+    if (more) {
 #pragma unroll
-    for (int k = 0; k < NPRE; ++k)
-      if (goff[k] >= 0) *reinterpret_cast<f32x4*>(xs + loff[k]) = pre[k];
-    __syncthreads();
-    if (c + 1 < c_end) {
-#pragma unroll
-      for (int k = 0; k < NPRE; ++k)
-        if (goff[k] >= 0) pre[k] = *reinterpret_cast<const f32x4*>(X + goff[k] + (long)(c + 1) * TC);
+      for (int k = 0; k < NPRE; ++k) pre[k] = *reinterpret_cast<const f32x4*>(X + goff[k] + (long)(c + 1) * TC);
     }
+    // LDS operands one J ahead of the MFMAs that consume them
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (NS == 1) {
+      float b0[4], b1[4];
 #pragma unroll
-    for (int J = 0; J < KJW; ++J) {
+      for (int s = 0; s < 4; ++s) { b0[s] = xrd[s * LSTR]; b1[s] = xrd[s * LSTR + 16]; }
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);  // the prologue reads form their own group
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const float a = areg[J][s];
-        const float b0 = xrd[(16 * J + s) * LSTR];
-        const float b1 = xrd[(16 * J + s) * LSTR + 16];
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc1, 0, 0, 0);
+      for (int J = 0; J < KJW; ++J) {
+        float n0[4], n1[4];
+        if (J + 1 < KJW) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) { n0[s] = xrd[(16 * (J + 1) + s) * LSTR]; n1[s] = xrd[(16 * (J + 1) + s) * LSTR + 16]; }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[J][s], b0[s], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[J][s], b1[s], acc1, 0, 0, 0);
+        }
+        // pin the order: the four LDS reads of step J+1, then the eight MFMAs of step J
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+        if (J + 1 < KJW) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) { b0[s] = n0[s]; b1[s] = n1[s]; }
+        }
       }
+    } else {
+      // one N tile per wave; two accumulator chains (s even / odd) cover the 40-cycle MFMA latency
+      float b0[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) b0[s] = xrd[s * LSTR];
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+      for (int J = 0; J < KJW; ++J) {
+        float n0[4];
+        if (J + 1 < KJW) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) n0[s] = xrd[(16 * (J + 1) + s) * LSTR];
+        }
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[J][0], b0[0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[J][1], b0[1], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[J][2], b0[2], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[J][3], b0[3], acc1, 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        if (J + 1 < KJW) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) b0[s] = n0[s];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc0[i] += acc1[i];
     }
     if (KS > 1) {
       // sum the K slices of the waves that share an M tile
@@ -131,23 +176,36 @@ __global__ __launch_bounds__(256 * KS) void tile_atx_kernel(const float* __restr
       float* o = outp + (long)c * TC;
       if (gridDim.z == 1) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { o[(long)i * ldo] = acc0[i]; o[(long)i * ldo + 16] = acc1[i]; }
+        for (int i = 0; i < 4; ++i) {
+          o[(long)i * ldo] = acc0[i];
+          if (NS == 1) o[(long)i * ldo + 16] = acc1[i];
+        }
       } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { atomicAdd(&o[(long)i * ldo], acc0[i]); atomicAdd(&o[(long)i * ldo + 16], acc1[i]); }
+        for (int i = 0; i < 4; ++i) {
+          atomicAdd(&o[(long)i * ldo], acc0[i]);
+          if (NS == 1) atomicAdd(&o[(long)i * ldo + 16], acc1[i]);
+        }
       }
+    }
+    if (!DB) __syncthreads();  // single buffer: everyone must be done reading before the refill
+    if (more) {
+      float* xw = lds + (DB ? (cur ^ 1) * (DPAD * LSTR) : 0);
+#pragma unroll
+      for (int k = 0; k < NPRE; ++k) *reinterpret_cast<f32x4*>(loff[k] == TRASH ? lds + TRASH : xw + loff[k]) = pre[k];
     }
     __syncthreads();
   }
 }
 
-template <int KJW, int KS>
+template <int KJW, int KS, int NS>
 static int launch_atx_variant(pmd_ctx* ctx, const float* X, long ldx, const int* pix, int pix_stride, long row0_stride,
                               int d, const float* A, long a_tile_stride, int a_ld, float* Out, long out_tile_stride,
                               long ldo, int n_tiles, int T, int slices, int kz) {
   constexpr int DPAD = 16 * KJW * KS;
-  const size_t lds = (size_t)(DPAD * 36 + (KS > 1 ? (KS - 1) * 4 * 2 * 256 : 0)) * sizeof(float);
-  auto kern = tile_atx_kernel<KJW, KS>;
+  constexpr bool DB = (2 * DPAD * 36 + (KS - 1) * 2048 + 4) * 4 <= 160 * 1024;
+  const size_t lds = (size_t)((DB ? 2 : 1) * DPAD * 36 + (KS > 1 ? (KS - 1) * 4 * 2 * 256 : 0) + 4) * sizeof(float);
+  auto kern = tile_atx_kernel<KJW, KS, NS>;
   PMD_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int n_chunks = (T + 31) / 32;
   if (slices < 1) slices = 1;
@@ -155,7 +213,7 @@ static int launch_atx_variant(pmd_ctx* ctx, const float* X, long ldx, const int*
   const int cps = (n_chunks + slices - 1) / slices;
   const int ny = (n_chunks + cps - 1) / cps;
   // tiles ride on gridDim.x (limit 2^31-1)
-  hipLaunchKernelGGL(kern, dim3(n_tiles, ny, kz), dim3(256 * KS), lds, ctx->stream, X, ldx, pix, pix_stride,
+  hipLaunchKernelGGL(kern, dim3(n_tiles, ny, kz), dim3(256 * KS * NS), lds, ctx->stream, X, ldx, pix, pix_stride,
                      row0_stride, d, A, a_tile_stride, a_ld, Out, out_tile_stride, ldo, n_chunks, cps);
   PMD_LAUNCH_CHECK(ctx, "tile_atx_kernel");
   return PMD_OK;
@@ -178,15 +236,15 @@ int pmd_launch_tile_atx(pmd_ctx* ctx, const float* X, long ldx, const int* pix, 
   pmd_dvariant v;
   if (!pmd_pick_dvariant(dv, &v)) return pmd_fail(ctx, PMD_ERR_UNSUPPORTED, "tile_atx", "no kernel variant");
   if (a_ld < kz * v.dpad) return pmd_fail(ctx, PMD_ERR_ARG, "tile_atx", "a_ld smaller than padded tile size");
-#define ATX_CASE(KJW_, KS_)                                                                                         \
-  if (v.kjw == KJW_ && v.ks == KS_)                                                                                 \
-    return launch_atx_variant<KJW_, KS_>(ctx, X, ldx, pix, pix_stride, row0_stride, d, A, a_tile_stride, a_ld, Out, \
-                                         out_tile_stride, ldo, n_tiles, T, slices, kz);
-  ATX_CASE(16, 1)
-  ATX_CASE(25, 1)
-  ATX_CASE(32, 1)
-  ATX_CASE(25, 2)
-  ATX_CASE(32, 2)
+#define ATX_CASE(KJW_, KS_, NS_)                                                                                         \
+  if (v.kjw == KJW_ && v.ks == KS_)                                                                                      \
+    return launch_atx_variant<KJW_, KS_, NS_>(ctx, X, ldx, pix, pix_stride, row0_stride, d, A, a_tile_stride, a_ld, Out, \
+                                              out_tile_stride, ldo, n_tiles, T, slices, kz);
+  ATX_CASE(16, 1, 2)
+  ATX_CASE(25, 1, 2)
+  ATX_CASE(32, 1, 1)
+  ATX_CASE(25, 2, 1)
+  ATX_CASE(32, 2, 1)
 #undef ATX_CASE
   return pmd_fail(ctx, PMD_ERR_UNSUPPORTED, "tile_atx", "variant not built");
 }
