@@ -560,9 +560,11 @@ __global__ __launch_bounds__(256) void gram_apply_kernel(const float* __restrict
   const int ra = ranks[a];
   if (ra == 0) return;
   const int x = blockIdx.x * 256 + threadIdx.x;
-  double acc[NOUT];
+  // fp32 accumulation over the few hundred terms of a block row: the product feeds fp32 GEMMs
+  // (the reference rounds its float64 U^T U v to float32 at decomposition.py:982)
+  float acc[NOUT];
 #pragma unroll
-  for (int c = 0; c < NOUT; ++c) acc[c] = 0.0;
+  for (int c = 0; c < NOUT; ++c) acc[c] = 0.f;
   for (int e = nbr_ptr[a]; e < nbr_ptr[a + 1]; ++e) {
     const int row0 = nbr[4 * e], rb = nbr[4 * e + 1], blk = nbr[4 * e + 2], flags = nbr[4 * e + 3];
     const float* src = (flags & 2) ? Gbg + (long)blk * 4096 : Gblk + (long)blk * 4096;
@@ -575,9 +577,9 @@ __global__ __launch_bounds__(256) void gram_apply_kernel(const float* __restrict
     __syncthreads();
     if (x < ncols) {
       for (int cp = 0; cp < rb; ++cp) {
-        const double v = (double)M[(long)(row0 + cp) * ldm + x];
+        const float v = M[(long)(row0 + cp) * ldm + x];
 #pragma unroll
-        for (int c = 0; c < NOUT; ++c) acc[c] = fma((double)g[cp][c], v, acc[c]);
+        for (int c = 0; c < NOUT; ++c) acc[c] = fmaf(g[cp][c], v, acc[c]);
       }
     }
   }
@@ -585,7 +587,7 @@ __global__ __launch_bounds__(256) void gram_apply_kernel(const float* __restrict
     const long off = col_off[a];
 #pragma unroll
     for (int c = 0; c < NOUT; ++c)
-      if (c < ra) GM[(off + c) * ldgm + x] = (float)acc[c];
+      if (c < ra) GM[(off + c) * ldgm + x] = acc[c];
   }
 }
 

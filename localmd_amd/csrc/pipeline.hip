@@ -106,7 +106,7 @@ int pmd_tiles_decompose_impl(pmd_ctx* ctx, const float* Xf, long ldx, long n_row
 
   // --- V_ds = U_ds^T X_ds; basis of its row space (decomposition.py:295-301)
   ctx->atx_label = "tile_atx_main";
-  RUN(pmd_launch_tile_atx(ctx, Xf, ldx, tile_pix, d, 0, d, p.ut0, s64d, p.dpad, p.outA, s64v, ldv, n, t_crop, 4));
+  RUN(pmd_launch_tile_atx(ctx, Xf, ldx, tile_pix, d, 0, d, p.ut0, s64d, p.dpad, p.outA, s64v, ldv, n, t_crop, 2));
   // (this Gram only conditions the basis change -- span(S) does not depend on it -- so fp32 MFMA is enough)
   RUN(pmd_launch_tile_xbt(ctx, p.outA, ldv, nullptr, 0, 64, 64, p.outA, s64v, ldv, p.g1f, GRAM_SLICES * 4096L, 4096, 64, n, t_crop, GRAM_SLICES));
   RUN(pmd_launch_gram_f2d(ctx, p.g1f, 64, (long)n * GRAM_SLICES, p.gpart));
@@ -121,7 +121,7 @@ int pmd_tiles_decompose_impl(pmd_ctx* ctx, const float* Xf, long ldx, long n_row
   RUN(pmd_launch_tile_rowmix(ctx, p.sst, s64d, p.dpad, p.nmat, 4096, r, r, p.sst, s64d, p.dpad, d, n));
 
   // --- W = U0^T X, its SVD rotates U0 and gives sigma*V (decomposition.py:318-323)
-  RUN(pmd_launch_tile_atx(ctx, Xf, ldx, tile_pix, d, 0, d, p.sst, s64d, p.dpad, V_out, s64v, ldv, n, t_crop, 4));
+  RUN(pmd_launch_tile_atx(ctx, Xf, ldx, tile_pix, d, 0, d, p.sst, s64d, p.dpad, V_out, s64v, ldv, n, t_crop, 2));
   ctx->atx_label = nullptr;
   RUN(pmd_launch_tile_gram(ctx, V_out, s64v, ldv, t_crop, n, GRAM_SLICES, p.gpart));
   RUN(pmd_launch_small_eig(ctx, p.gpart, GRAM_SLICES, r, 0, 0.0, p.nmat, sing_out ? sing_out : p.lam, n));

@@ -37,15 +37,18 @@ int pmd_init_tables(pmd_ctx* ctx) {
 
 __device__ __forceinline__ int bitrev7(int x) { return (int)(__brev((unsigned)x) >> 25); }
 
-// One wave = 64 consecutive pixels x one 1024-frame chunk.  Every lane runs its own pixel's
-// Welch estimate; its 128-point complex FFT lives in an LDS column (index*64 + lane), so lanes
-// never share a bank and no barrier is needed.
+// One wave = 64 consecutive pixels x one 1024-frame chunk.  Every lane runs its own pixel's Welch
+// estimate; its 128-point complex FFT (real-input trick: z[n] = y[2n] + i y[2n+1]) lives in an LDS
+// column of float2 (index*64 + lane): lanes never share a bank, no barrier is needed, and every
+// butterfly is two ds_read_b64 + one broadcast twiddle read + two ds_write_b64.
 __global__ __launch_bounds__(64) void stats_chunk_kernel(const float* __restrict__ Y, int T, long D, int frame_const,
                                                          int do_noise, const float* __restrict__ tab,
                                                          double* __restrict__ chunk_sum, float* __restrict__ chunk_noise) {
-  extern __shared__ float lds[];
-  float* re = lds;
-  float* im = lds + 128 * 64;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float2* z = reinterpret_cast<float2*>(lds);            // [128][64]
+  float2* tw = z + 128 * 64;                             // [64]  exp(-2 pi i k / 128)
+  float2* tw256 = tw + 64;                               // [129] exp(-2 pi i k / 256)
+  float* win = reinterpret_cast<float*>(tw256 + 130);    // [256]
   const int lane = threadIdx.x;
   const long c = (long)blockIdx.x * 64 + lane;
   const bool valid = c < D;
@@ -55,61 +58,89 @@ __global__ __launch_bounds__(64) void stats_chunk_kernel(const float* __restrict
   const int t1 = min(T, t0 + frame_const);
   const int n = t1 - t0;
 
+  // batches of 32 independent loads per lane (the pass is latency bound otherwise: two waves per CU)
   double s = 0.0;
-  for (int t = t0; t < t1; ++t) s += (double)Y[(long)t * D + cc];
+  int t = t0;
+  for (; t + 32 <= t1; t += 32) {
+    float v[32];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) v[u] = Y[(long)(t + u) * D + cc];
+    double part = 0.0;
+#pragma unroll
+    for (int u = 0; u < 32; ++u) part += (double)v[u];
+    s += part;
+  }
+  for (; t < t1; ++t) s += (double)Y[(long)t * D + cc];
   if (valid) chunk_sum[(long)chunk * D + c] = s;
   if (!do_noise || n < 256) {
     if (valid && do_noise) chunk_noise[(long)chunk * D + c] = 0.f;
     return;
   }
+  tw[lane] = make_float2(tab[TAB_C128 + lane], -tab[TAB_S128 + lane]);
+  for (int k = lane; k <= 128; k += 64) tw256[k] = make_float2(tab[TAB_C256 + k], -tab[TAB_S256 + k]);
+  for (int i = lane; i < 256; i += 64) win[i] = tab[TAB_WIN + i];
+  __builtin_amdgcn_s_waitcnt(0);
+  __builtin_amdgcn_wave_barrier();
+
   const int nseg = (n - 128) / 128;
   float acc = 0.f;
   for (int seg = 0; seg < nseg; ++seg) {
     const float* yp = Y + (long)(t0 + seg * 128) * D + cc;
     double msum = 0.0;
-    for (int i = 0; i < 256; ++i) msum += (double)yp[(long)i * D];
+    for (int i = 0; i < 256; i += 32) {
+      float v[32];
+#pragma unroll
+      for (int u = 0; u < 32; ++u) v[u] = yp[(long)(i + u) * D];
+      double part = 0.0;
+#pragma unroll
+      for (int u = 0; u < 32; ++u) part += (double)v[u];
+      msum += part;
+    }
     const float m = (float)(msum * (1.0 / 256.0));
-    for (int i = 0; i < 256; i += 2) {
-      const int pos = bitrev7(i >> 1) * 64 + lane;
-      re[pos] = (yp[(long)i * D] - m) * tab[TAB_WIN + i];
-      im[pos] = (yp[(long)(i + 1) * D] - m) * tab[TAB_WIN + i + 1];
+    for (int i = 0; i < 128; i += 16) {
+      float va[16], vb[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) { va[u] = yp[(long)(2 * (i + u)) * D]; vb[u] = yp[(long)(2 * (i + u) + 1) * D]; }
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        z[bitrev7(i + u) * 64 + lane] = make_float2((va[u] - m) * win[2 * (i + u)], (vb[u] - m) * win[2 * (i + u) + 1]);
     }
     // radix-2 decimation-in-time, in place
 #pragma unroll 1
     for (int half = 1; half < 128; half <<= 1) {
       const int tw_step = 64 / half;
-#pragma unroll 4
+#pragma unroll 8
       for (int j = 0; j < 64; ++j) {
         const int k = j & (half - 1);
         const int i0 = ((j - k) << 1) + k;
         const int i1 = i0 + half;
-        const float wr = tab[TAB_C128 + k * tw_step];
-        const float wi = -tab[TAB_S128 + k * tw_step];
-        const float ar = re[i0 * 64 + lane], ai = im[i0 * 64 + lane];
-        const float br = re[i1 * 64 + lane], bi = im[i1 * 64 + lane];
-        const float tr = br * wr - bi * wi;
-        const float ti = br * wi + bi * wr;
-        re[i0 * 64 + lane] = ar + tr;
-        im[i0 * 64 + lane] = ai + ti;
-        re[i1 * 64 + lane] = ar - tr;
-        im[i1 * 64 + lane] = ai - ti;
+        const float2 w = tw[k * tw_step];
+        const float2 a = z[i0 * 64 + lane];
+        const float2 b = z[i1 * 64 + lane];
+        const float tr = b.x * w.x - b.y * w.y;
+        const float ti = b.x * w.y + b.y * w.x;
+        z[i0 * 64 + lane] = make_float2(a.x + tr, a.y + ti);
+        z[i1 * 64 + lane] = make_float2(a.x - tr, a.y - ti);
       }
     }
     // real-input unpack for bins 65..128: sum of one-sided power (x2 except Nyquist)
     float p = 0.f;
+#pragma unroll 4
     for (int k = 65; k < 128; ++k) {
-      const float zr = re[k * 64 + lane], zi = im[k * 64 + lane];
-      const float cr = re[(128 - k) * 64 + lane], ci = -im[(128 - k) * 64 + lane];
-      const float er = 0.5f * (zr + cr), ei = 0.5f * (zi + ci);
+      const float2 zk = z[k * 64 + lane];
+      const float2 zc = z[(128 - k) * 64 + lane];
+      const float cr = zc.x, ci = -zc.y;
+      const float er = 0.5f * (zk.x + cr), ei = 0.5f * (zk.y + ci);
       // O = (Z - conj(Z'))/(2i) = (-i/2) * (dr + i di) = (di/2, -dr/2)
-      const float dr = zr - cr, di = zi - ci;
+      const float dr = zk.x - cr, di = zk.y - ci;
       const float orr = 0.5f * di, oi = -0.5f * dr;
-      const float wr = tab[TAB_C256 + k], wi = -tab[TAB_S256 + k];
-      const float xr = er + (orr * wr - oi * wi);
-      const float xi = ei + (orr * wi + oi * wr);
+      const float2 w = tw256[k];
+      const float xr = er + (orr * w.x - oi * w.y);
+      const float xi = ei + (orr * w.y + oi * w.x);
       p += 2.0f * (xr * xr + xi * xi);
     }
-    const float xn = re[lane] - im[lane];
+    const float2 z0 = z[lane];
+    const float xn = z0.x - z0.y;
     p += xn * xn;
     acc += p;
   }
@@ -155,7 +186,7 @@ int pmd_launch_stats(pmd_ctx* ctx, const float* movie, int T, long D, int frame_
     const int n = (k + 1 == nchunks) ? T - k * frame_const : frame_const;
     if (n >= 256) ncounted++;
   }
-  const size_t lds = 2 * 128 * 64 * sizeof(float);
+  const size_t lds = 2 * 128 * 64 * sizeof(float) + (64 + 130) * sizeof(float2) + 256 * sizeof(float) + 64;
   PMD_HIP(ctx, hipFuncSetAttribute((const void*)stats_chunk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(stats_chunk_kernel, dim3((unsigned)((D + 63) / 64), nchunks), dim3(64), lds, ctx->stream, movie, T,
                      D, frame_const, do_noise, ctx->tables, csum, cnoise);
@@ -209,20 +240,26 @@ int pmd_launch_standardize_transpose(pmd_ctx* ctx, const float* movie, long D, c
 }
 
 // ---- background filter: out[c][f] = in[c][f] - sum_k basis[c][k] * pj[k][f] ----------------
-// basis is [c][k] row-major (ldb = K); pj is [k][f] with leading dimension ldp.
+// basis is [c][k] row-major (ldb = K); pj is [k][f] with leading dimension ldp.  A thread owns one
+// frame column: its K projections stay in registers while the workgroup walks 64 pixel rows, so the
+// pass is one read + one write of the movie (the basis row is a wave-uniform broadcast load).
 template <int KMAX>
 __global__ __launch_bounds__(256) void filter_kernel(const float* __restrict__ in, float* __restrict__ out, long D,
                                                      int nf, long ld, const float* __restrict__ basis, int K,
                                                      const float* __restrict__ pj, long ldp) {
-  const long c = blockIdx.y;
-  float b[KMAX];
+  const long f = (long)blockIdx.x * 256 + threadIdx.x;
+  const long c0 = (long)blockIdx.y * 64;
+  if (f >= nf) return;
+  float p[KMAX];
 #pragma unroll
-  for (int k = 0; k < KMAX; ++k) b[k] = (k < K) ? basis[c * K + k] : 0.f;
-  for (long f = (long)blockIdx.x * blockDim.x + threadIdx.x; f < nf; f += (long)gridDim.x * blockDim.x) {
+  for (int k = 0; k < KMAX; ++k) p[k] = (k < K) ? pj[(long)k * ldp + f] : 0.f;
+  const long c1 = (c0 + 64 < D) ? c0 + 64 : D;
+  for (long c = c0; c < c1; ++c) {
+    const float* b = basis + c * K;
     float acc = 0.f;
 #pragma unroll
     for (int k = 0; k < KMAX; ++k)
-      if (k < K) acc = fmaf(b[k], pj[(long)k * ldp + f], acc);
+      if (k < K) acc = fmaf(b[k], p[k], acc);
     out[c * ld + f] = in[c * ld + f] - acc;
   }
 }
@@ -231,17 +268,16 @@ int pmd_launch_filter(pmd_ctx* ctx, const float* in, float* out, long D, int nf,
                       const float* pj, long ldp) {
   pmd_prof_scope prof__(ctx, "bg_filter");
   if (K > 64) return pmd_fail(ctx, PMD_ERR_UNSUPPORTED, "pmd_filter", "background rank > 64");
-  int bx = (nf + 255) / 256;
-  if (bx > 8) bx = 8;
-  // gridDim.y is limited to 65535: walk the pixels in slabs
-  for (long c0 = 0; c0 < D; c0 += 32768) {
-    const long cn = (D - c0 < 32768) ? D - c0 : 32768;
-    dim3 grid(bx, (unsigned)cn);
+  const int bx = (nf + 255) / 256;
+  const long rows_per_launch = 65535L * 64;
+  for (long c0 = 0; c0 < D; c0 += rows_per_launch) {
+    const long cn = (D - c0 < rows_per_launch) ? D - c0 : rows_per_launch;
+    dim3 grid(bx, (unsigned)((cn + 63) / 64));
     if (K <= 16)
-      hipLaunchKernelGGL(filter_kernel<16>, grid, dim3(256), 0, ctx->stream, in + c0 * ld, out + c0 * ld, D, nf, ld,
+      hipLaunchKernelGGL(filter_kernel<16>, grid, dim3(256), 0, ctx->stream, in + c0 * ld, out + c0 * ld, cn, nf, ld,
                          basis + c0 * K, K, pj, ldp);
     else
-      hipLaunchKernelGGL(filter_kernel<64>, grid, dim3(256), 0, ctx->stream, in + c0 * ld, out + c0 * ld, D, nf, ld,
+      hipLaunchKernelGGL(filter_kernel<64>, grid, dim3(256), 0, ctx->stream, in + c0 * ld, out + c0 * ld, cn, nf, ld,
                          basis + c0 * K, K, pj, ldp);
     PMD_LAUNCH_CHECK(ctx, "filter_kernel");
   }

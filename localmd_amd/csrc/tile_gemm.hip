@@ -241,7 +241,7 @@ int pmd_launch_tile_atx(pmd_ctx* ctx, const float* X, long ldx, const int* pix, 
     return launch_atx_variant<KJW_, KS_, NS_>(ctx, X, ldx, pix, pix_stride, row0_stride, d, A, a_tile_stride, a_ld, Out, \
                                               out_tile_stride, ldo, n_tiles, T, slices, kz);
   ATX_CASE(16, 1, 2)
-  ATX_CASE(25, 1, 2)
+  ATX_CASE(25, 1, 1)
   ATX_CASE(32, 1, 1)
   ATX_CASE(25, 2, 1)
   ATX_CASE(32, 2, 1)

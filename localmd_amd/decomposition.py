@@ -626,7 +626,7 @@ def localmd_decomposition(
         else:
             del v_dev
             proj = torch.empty((n_tiles, 64, ld_T), dtype=torch.float32, device=ctx.device)
-        ctx.call("pmd_tiles_project", ptr(xs_full), ld_T, T, ptr(pix_dev), n_tiles, d, ptr(uw_dev), dpad, ptr(proj), ld_T, 4)
+        ctx.call("pmd_tiles_project", ptr(xs_full), ld_T, T, ptr(pix_dev), n_tiles, d, ptr(uw_dev), dpad, ptr(proj), ld_T, 2)
         Z = torch.zeros((Rc, T), dtype=torch.float32, device=ctx.device)
         ctx.call("pmd_compact_rows", ptr(proj), ld_T, ptr(col_off_dev), ptr(ranks_dev), T, ptr(Z), T, n_tiles)
         if K > 0:
