@@ -182,25 +182,28 @@ __global__ __launch_bounds__(256) void small_eig_kernel(const double* __restrict
         pq[2 * tid] = p; pq[2 * tid + 1] = q;
       }
       __syncthreads();
-      for (int i = tid; i < half * n; i += 256) {
-        const int k = i / n, j = i - k * n;
-        const double c = cs[2 * k], s = cs[2 * k + 1];
-        if (s != 0.0) {
-          const int p = pq[2 * k], q = pq[2 * k + 1];
-          const double ap = A[p * EIG_LD + j], aq = A[q * EIG_LD + j];
-          A[p * EIG_LD + j] = c * ap - s * aq;
-          A[q * EIG_LD + j] = s * ap + c * aq;
+      // A <- J^T A J in one pass: the 2x2 block (pair k rows) x (pair k' columns) gets both rotations;
+      // blocks are disjoint, so one barrier per step suffices.  V <- V J rides in the same phase.
+      for (int i = tid; i < half * half; i += 256) {
+        const int k = i / half, kp = i - k * half;
+        const double c = cs[2 * k], s = cs[2 * k + 1], c2 = cs[2 * kp], s2 = cs[2 * kp + 1];
+        if (s != 0.0 || s2 != 0.0) {
+          const int p = pq[2 * k], q = pq[2 * k + 1], p2 = pq[2 * kp], q2 = pq[2 * kp + 1];
+          const double a11 = A[p * EIG_LD + p2], a12 = A[p * EIG_LD + q2];
+          const double a21 = A[q * EIG_LD + p2], a22 = A[q * EIG_LD + q2];
+          const double r11 = c * a11 - s * a21, r12 = c * a12 - s * a22;   // rows rotated
+          const double r21 = s * a11 + c * a21, r22 = s * a12 + c * a22;
+          A[p * EIG_LD + p2] = c2 * r11 - s2 * r12;
+          A[p * EIG_LD + q2] = s2 * r11 + c2 * r12;
+          A[q * EIG_LD + p2] = c2 * r21 - s2 * r22;
+          A[q * EIG_LD + q2] = s2 * r21 + c2 * r22;
         }
       }
-      __syncthreads();
       for (int i = tid; i < half * n; i += 256) {
         const int k = i / n, j = i - k * n;
         const double c = cs[2 * k], s = cs[2 * k + 1];
         if (s != 0.0) {
           const int p = pq[2 * k], q = pq[2 * k + 1];
-          const double ap = A[j * EIG_LD + p], aq = A[j * EIG_LD + q];
-          A[j * EIG_LD + p] = c * ap - s * aq;
-          A[j * EIG_LD + q] = s * ap + c * aq;
           const double vp = V[j * EIG_LD + p], vq = V[j * EIG_LD + q];
           V[j * EIG_LD + p] = c * vp - s * vq;
           V[j * EIG_LD + q] = s * vp + c * vq;

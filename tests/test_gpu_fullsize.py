@@ -1,0 +1,109 @@
+"""
+BASELINE-size runs (GPU): the oracle cannot finish these shapes in seconds, so the HIP path is
+checked through size-independent properties of the decomposition Y ~ mean + std * ([UR] diag(s) Vt):
+orthonormal [UR] and Vt (probed on random column/row subsets), sorted non-negative singular values,
+canonical CSR structure consistent with the tile ranks, denoising against the noiseless ground truth
+of the synthetic movie, and run-to-run determinism.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _decompose(gpu_ctx, T, d1, d2, block, max_components, seed=11):
+    import torch
+    import localmd_amd
+    from localmd_amd import decomposition as Dm
+    from localmd_amd.synthetic import make_movie_torch
+
+    Dm.QUIET = True
+    dev = gpu_ctx.device
+    noisy = make_movie_torch(T, d1, d2, dev, seed=0, noise=1.0)
+    np.random.seed(0)
+    pmd, diag = localmd_amd.localmd_decomposition(noisy, (block, block), T, max_components=max_components, seed=seed,
+                                                  ctx=gpu_ctx, return_diagnostics=True, sim_iters=50)
+    return pmd, diag, noisy
+
+
+def _check_properties(pmd, diag, noisy, T, d1, d2, block):
+    import torch
+    from localmd_amd.synthetic import make_movie_torch
+    from localmd_amd import grid
+
+    D = d1 * d2
+    rng = np.random.default_rng(0)
+    # structure: canonical CSR, column count = sum of tile ranks + background columns
+    u = pmd.u
+    it1, it2 = grid.tile_origins((d1, d2), (block, block))
+    assert len(diag["tile_ranks"]) == len(it1) * len(it2)
+    assert np.all(diag["tile_ranks"] >= 1) and np.all(diag["tile_ranks"] <= diag["max_components"])
+    assert u.shape == (D, int(diag["tile_ranks"].sum()) + 15)
+    assert u.indptr[0] == 0 and np.all(np.diff(u.indptr) > 0) and u.indptr[-1] == u.nnz
+    rows = rng.integers(0, D, 2000)
+    for r_ in rows[:200]:
+        seg = u.indices[u.indptr[r_]:u.indptr[r_ + 1]]
+        assert np.all(np.diff(seg) > 0)
+    assert u.data.dtype == np.float64 and u.indices.dtype == np.int32 and np.all(np.isfinite(u.data))
+    # every pixel is covered by 1..9 tiles plus the 15 background entries
+    per_row = np.diff(u.indptr)
+    assert per_row.min() >= 16 and per_row.max() <= 9 * diag["max_components"] + 15
+    # spectrum
+    s = pmd.s
+    assert np.all(np.isfinite(s)) and np.all(s > 0) and np.all(np.diff(s) <= 1e-3 * s[0])
+    assert pmd.r.shape == (u.shape[1], len(s)) and pmd.v.shape == (len(s), T)
+    # orthonormality probes
+    cols = np.sort(rng.choice(len(s), size=min(48, len(s)), replace=False))
+    ur = u @ pmd.r[:, cols]
+    g = np.abs(ur.T @ ur - np.eye(len(cols)))
+    tol_u = 2e-2 + 4e-7 * (s[0] / s[cols]) ** 2
+    assert np.all(g <= np.maximum(tol_u[:, None], tol_u[None, :])), g.max()
+    strong = cols[s[cols] > 0.1 * s[0]]
+    if len(strong) > 1:
+        us = u @ pmd.r[:, strong]
+        assert np.abs(us.T @ us - np.eye(len(strong))).max() < 2e-3
+    # Vt = W^T V / s comes from an fp32 Gram eigendecomposition (decomposition.py:1089-1097): component c is
+    # orthonormal only to ~eps * (s_1 / s_c)^2, in the reference as well
+    vr = pmd.v[cols]
+    dev_v = np.abs(vr @ vr.T - np.eye(len(cols)))
+    tol_c = 5e-3 + 4e-7 * (s[0] / s[cols]) ** 2
+    assert np.all(dev_v <= np.maximum(tol_c[:, None], tol_c[None, :])), dev_v.max()
+    # denoising: on random probes the reconstruction is closer to the noiseless movie than the input is
+    clean = make_movie_torch(T, d1, d2, noisy.device, seed=0, noise=0.0)
+    pi = rng.integers(0, d1, 300)
+    pj = rng.integers(0, d2, 300)
+    err_rec, err_in = [], []
+    for a, b in zip(pi[:40], pj[:40]):
+        trace = pmd[:, int(a), int(b)]
+        c = clean[:, a, b].cpu().numpy()
+        y = noisy[:, a, b].cpu().numpy()
+        err_rec.append(np.mean((trace - c) ** 2))
+        err_in.append(np.mean((y - c) ** 2))
+    assert np.mean(err_rec) < 0.6 * np.mean(err_in), (np.mean(err_rec), np.mean(err_in))
+    # statistics images
+    assert abs(float(pmd.var_img.mean()) - 1.0) < 0.1  # Welch noise sigma of the N(0,1) noise
+    assert abs(float(pmd.mean_img.mean()) - float(noisy[:200].mean())) < 1.0
+
+
+def test_config2_256x256x2000_properties_and_determinism(gpu_ctx):
+    T, d1, d2, block = 2000, 256, 256, 20
+    pmd, diag, noisy = _decompose(gpu_ctx, T, d1, d2, block, 8)
+    _check_properties(pmd, diag, noisy, T, d1, d2, block)
+    pmd2, diag2, _ = _decompose(gpu_ctx, T, d1, d2, block, 8)
+    np.testing.assert_array_equal(diag["tile_ranks"], diag2["tile_ranks"])
+    np.testing.assert_array_equal(pmd.u.indices, pmd2.u.indices)
+    np.testing.assert_array_equal(pmd.u.data, pmd2.u.data)
+    np.testing.assert_allclose(pmd.s, pmd2.s, rtol=1e-5)
+
+
+def test_config3_512x512x10000_properties(gpu_ctx):
+    import torch
+
+    free, total = torch.cuda.mem_get_info()
+    if total < 150 * 2 ** 30:
+        pytest.skip("needs an MI355X-class HBM capacity")
+    T, d1, d2, block = 10000, 512, 512, 20
+    pmd, diag, noisy = _decompose(gpu_ctx, T, d1, d2, block, 50)
+    assert len(diag["tile_ranks"]) == 2601
+    _check_properties(pmd, diag, noisy, T, d1, d2, block)
+    gpu_ctx.release_workspace()
