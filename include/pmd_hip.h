@@ -160,7 +160,8 @@ int pmd_orthogonalize_factored(pmd_ctx* ctx, const float* M, int Rc, int m, long
  * *ok_host = 0 if the matrix is not numerically positive definite (use pmd_orthogonalize_factored then). */
 int pmd_orthogonalize_chol(pmd_ctx* ctx, const float* M, int Rc, int m, long ldm, const float* GM, long ldgm,
                            float* Et_out, long lde, int* ok_host, void* ws, size_t ws_bytes);
-size_t pmd_projected_svd_factored_workspace_bytes(int m, int rp, int T);
+size_t pmd_orthogonalize_chol_workspace_bytes(int Rc, int m);
+size_t pmd_projected_svd_factored_workspace_bytes(int Rc, int m, int rp, int T);
 int pmd_projected_svd_factored(pmd_ctx* ctx, const float* M, int Rc, int m, long ldm, const float* Et, int rp, long lde,
                                const float* Z, int T, long ldz, float* R_out, long ldr, float* s_out, float* Vt_out,
                                long ldvt, float* Vp_out, long ldvp, void* ws, size_t ws_bytes);

@@ -273,8 +273,9 @@ int pmd_orthogonalize_chol(pmd_ctx* ctx, const float* M, int Rc, int m, long ldm
   CTX_CHECK(ctx);
   return pmd_orthogonalize_chol_impl(ctx, M, Rc, m, ldm, GM, ldgm, Et_out, lde, ok_host, ws, ws_bytes);
 }
-size_t pmd_projected_svd_factored_workspace_bytes(int m, int rp, int T) {
-  return pmd_projected_svd_factored_workspace_bytes_impl(m, rp, T);
+size_t pmd_orthogonalize_chol_workspace_bytes(int Rc, int m) { return pmd_orthogonalize_chol_workspace_bytes_impl(Rc, m); }
+size_t pmd_projected_svd_factored_workspace_bytes(int Rc, int m, int rp, int T) {
+  return pmd_projected_svd_factored_workspace_bytes_impl(Rc, m, rp, T);
 }
 int pmd_projected_svd_factored(pmd_ctx* ctx, const float* M, int Rc, int m, long ldm, const float* Et, int rp, long lde,
                                const float* Z, int T, long ldz, float* R_out, long ldr, float* s_out, float* Vt_out,

@@ -779,9 +779,9 @@ int pmd_orthogonalize_factored_impl(pmd_ctx* ctx, const float* M, int Rc, int m,
   return PMD_OK;
 }
 
-size_t pmd_projected_svd_factored_workspace_bytes_impl(int m, int rp, int T) {
+size_t pmd_projected_svd_factored_workspace_bytes_impl(int Rc, int m, int rp, int T) {
   return (size_t)m * T * sizeof(float) + (size_t)rp * T * sizeof(float) + (size_t)m * rp * sizeof(float) +
-         pmd_projected_svd_workspace_bytes_impl(1, rp, T) + 16384;
+         (size_t)m * Rc * sizeof(float) + pmd_projected_svd_workspace_bytes_impl(1, rp, T) + 16384;
 }
 
 // M: Rc x m; Et: rp x m; Z: Rc x T.  Outputs R_out (Rc x nk), s (nk), Vt (nk x T), nk = min(rp, T);
@@ -795,10 +795,15 @@ int pmd_projected_svd_factored_impl(pmd_ctx* ctx, const float* M, int Rc, int m,
   float* Vp = Vp_out ? Vp_out : ar.take_n<float>((size_t)rp * T);
   const long ldv = Vp_out ? ldvp : T;
   float* X1 = ar.take_n<float>((size_t)m * rp);
+  float* Mt = ar.take_n<float>((size_t)m * Rc);
   const size_t sub_bytes = pmd_projected_svd_workspace_bytes_impl(1, rp, T);
   void* sub = ar.take(sub_bytes);
   if (ar.overflow) return pmd_fail(ctx, PMD_ERR_WORKSPACE, "pmd_projected_svd_factored", "workspace too small");
-  RUN(pmd_gemm_rm(ctx, 1, 0, m, T, Rc, 1.f, M, ldm, Z, ldz, 0.f, W1, T));      // M^T Z
+  // M^T Z as a plain (non-transposed) product of an explicit copy of M^T: rocBLAS' transposed-A kernels
+  // reach half the rate of the plain ones at K = Rc ~ 5e4 (72 vs 147 TFLOP/s, scripts/gemm_probe.hip),
+  // and the copy is one 2 x 4 Rc m byte pass
+  RUN(launch_transpose(ctx, M, ldm, Rc, m, Mt, Rc));
+  RUN(pmd_gemm_rm(ctx, 0, 0, m, T, Rc, 1.f, Mt, Rc, Z, ldz, 0.f, W1, T));      // M^T Z
   RUN(pmd_gemm_rm(ctx, 0, 0, rp, T, m, 1.f, Et, lde, W1, T, 0.f, Vp, ldv));     // V = Et (M^T Z)
   // SVD of V with the identity as projection: the "R" it returns is W (rp x rp), reuse W1's memory
   float* Wmat = W1;  // rp x rp  (rp <= m, T)
@@ -822,13 +827,23 @@ __global__ void tril_mask_kernel(float* __restrict__ A, long ld, int n) {
     if (j > i) A[(long)i * ld + j] = 0.f;
 }
 
+size_t pmd_orthogonalize_chol_workspace_bytes_impl(int Rc, int m) { return (size_t)m * Rc * sizeof(float) + 8192; }
+
 int pmd_orthogonalize_chol_impl(pmd_ctx* ctx, const float* M, int Rc, int m, long ldm, const float* GM, long ldgm,
                                 float* Et_out, long lde, int* ok_host, void* ws, size_t ws_bytes) {
   pmd_arena ar(ws, ws_bytes);
   int* info = ar.take_n<int>(4);
+  float* Mt = ar.take_n<float>((size_t)m * Rc);
   if (ar.overflow) return pmd_fail(ctx, PMD_ERR_WORKSPACE, "pmd_orthogonalize_chol", "workspace too small");
   *ok_host = 0;
-  RUN(pmd_gemm_rm(ctx, 1, 0, m, m, Rc, 1.f, M, ldm, GM, ldgm, 0.f, Et_out, lde));
+  // C = M^T (G M): only the row-major lower triangle (= the column-major upper one potrf reads) is
+  // formed, in row blocks C[i0:i0+bs, 0:i0+bs] = Mt[i0:i0+bs, :] GM[:, 0:i0+bs]  (9/16 of the flops at 8 blocks)
+  RUN(launch_transpose(ctx, M, ldm, Rc, m, Mt, Rc));
+  const int bs = std::max(256, ((m + 7) / 8 + 255) / 256 * 256);
+  for (int i0 = 0; i0 < m; i0 += bs) {
+    const int rows = std::min(bs, m - i0);
+    RUN(pmd_gemm_rm(ctx, 0, 0, rows, i0 + rows, Rc, 1.f, Mt + (long)i0 * Rc, Rc, GM, ldgm, 0.f, Et_out + (long)i0 * lde, lde));
+  }
   int hinfo = 0;
   {
     pmd_prof_scope prof__(ctx, "rocsolver_spotrf");

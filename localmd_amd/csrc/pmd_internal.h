@@ -105,7 +105,8 @@ int pmd_csr_fill_impl(pmd_ctx* ctx, int d1, int d2, int order_f, int b1, const i
 size_t pmd_orthogonalize_factored_workspace_bytes_impl(int m);
 int pmd_orthogonalize_factored_impl(pmd_ctx* ctx, const float* M, int Rc, int m, long ldm, const float* GM, long ldgm,
                                     float* Et_out, long lde, int* rprime_out, void* ws, size_t ws_bytes);
-size_t pmd_projected_svd_factored_workspace_bytes_impl(int m, int rp, int T);
+size_t pmd_projected_svd_factored_workspace_bytes_impl(int Rc, int m, int rp, int T);
+size_t pmd_orthogonalize_chol_workspace_bytes_impl(int Rc, int m);
 int pmd_projected_svd_factored_impl(pmd_ctx* ctx, const float* M, int Rc, int m, long ldm, const float* Et, int rp,
                                     long lde, const float* Z, int T, long ldz, float* R_out, long ldr, float* s_out,
                                     float* Vt_out, long ldvt, float* Vp_out, long ldvp, void* ws, size_t ws_bytes);

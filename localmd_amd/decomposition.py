@@ -590,7 +590,7 @@ def localmd_decomposition(
                     m_eff = m_cols - 1
                 gram_apply(m_eff)
                 ok_c = c_i(0)
-                ws = ctx.workspace(4096)
+                ws = ctx.workspace(lib.pmd_orthogonalize_chol_workspace_bytes(Rc, m_eff))
                 ctx.call("pmd_orthogonalize_chol", ptr(right), Rc, m_eff, ld_right, ptr(GM), m_cols, ptr(Et_dev), m_cols,
                          C.byref(ok_c), ptr(ws), ws.numel())
                 chol_ok = bool(ok_c.value)
@@ -653,7 +653,7 @@ def localmd_decomposition(
             R_out = torch.empty((Rc, nk), dtype=torch.float32, device=ctx.device)
             s_out = torch.empty((nk,), dtype=torch.float32, device=ctx.device)
             Vt_out = torch.empty((nk, T), dtype=torch.float32, device=ctx.device)
-            ws = ctx.workspace(lib.pmd_projected_svd_factored_workspace_bytes(m_used, rp, T))
+            ws = ctx.workspace(lib.pmd_projected_svd_factored_workspace_bytes(Rc, m_used, rp, T))
             ctx.call("pmd_projected_svd_factored", ptr(right), Rc, m_used, m_cols, ptr(Et_dev), rp, m_cols, ptr(Z), T, T,
                      ptr(R_out), nk, ptr(s_out), ptr(Vt_out), T, ptr(Vp), T, ptr(ws), ws.numel())
         else:
