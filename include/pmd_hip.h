@@ -200,6 +200,10 @@ int pmdk_tile_pool_bin(pmd_ctx* ctx, const float* X, long ldx, long n_rows, cons
 int pmdk_roughness(pmd_ctx* ctx, const float* Ut, long u_tile_stride, int u_ld, int b1, int b2, const float* V,
                    long v_tile_stride, long v_ld, int T, int r, float* stats, int n_tiles);
 int pmdk_syevd(pmd_ctx* ctx, int n, float* A, long lda, float* w, float* work, int* info);
+/* Householder tridiagonalisation A = Q T Q^T with LAPACK ssytrd('L') conventions on the column-major view
+ * of the buffer (memory row c holds A(r, c), r >= c, at offset r): d[n], e[n-1], tau[n-1], reflectors in A.
+ * impl 0 = rocSOLVER, 1 = the library's own kernels (lda % 4 == 0, lda >= round_up(n, 4)). */
+int pmdk_sytrd(pmd_ctx* ctx, int n, float* A, long lda, float* d, float* e, float* tau, int impl);
 
 #ifdef __cplusplus
 }

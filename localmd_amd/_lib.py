@@ -75,6 +75,7 @@ SIGNATURES = {
     "pmdk_tile_pool_bin": (c_i, [c_p, c_p, c_l, c_l, c_p, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_l, c_l]),
     "pmdk_roughness": (c_i, [c_p, c_p, c_l, c_i, c_i, c_i, c_p, c_l, c_l, c_i, c_i, c_p, c_i]),
     "pmdk_syevd": (c_i, [c_p, c_i, c_p, c_l, c_p, c_p, c_p]),
+    "pmdk_sytrd": (c_i, [c_p, c_i, c_p, c_l, c_p, c_p, c_p, c_i]),
 }
 
 _lib = None

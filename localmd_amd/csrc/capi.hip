@@ -19,6 +19,8 @@ int pmd_ctx_create(int device, void* hip_stream, pmd_ctx** out) {
   ctx->device = device;
   ctx->stream = (hipStream_t)hip_stream;
   ctx->tables = nullptr;
+  ctx->scratch = nullptr;
+  ctx->scratch_bytes = 0;
   ctx->blas = nullptr;
   ctx->err[0] = 0;
   ctx->profile = false;
@@ -35,6 +37,7 @@ int pmd_ctx_destroy(pmd_ctx* ctx) {
   CTX_CHECK(ctx);
   hipSetDevice(ctx->device);
   if (ctx->tables) hipFree(ctx->tables);
+  if (ctx->scratch) hipFree(ctx->scratch);
   if (ctx->blas) rocblas_destroy_handle(ctx->blas);
   delete ctx;
   return PMD_OK;
@@ -331,6 +334,11 @@ int pmdk_roughness(pmd_ctx* ctx, const float* Ut, long u_tile_stride, int u_ld, 
 int pmdk_syevd(pmd_ctx* ctx, int n, float* A, long lda, float* w, float* work, int* info) {
   CTX_CHECK(ctx);
   return pmd_syevd(ctx, n, A, lda, w, work, info);
+}
+
+int pmdk_sytrd(pmd_ctx* ctx, int n, float* A, long lda, float* d, float* e, float* tau, int impl) {
+  CTX_CHECK(ctx);
+  return pmd_sytrd_auto(ctx, n, A, lda, d, e, tau, impl);
 }
 
 }  // extern "C"

@@ -32,14 +32,6 @@ int pmd_gemm_rm(pmd_ctx* ctx, int transA, int transB, int m, int n, int k, float
   return PMD_OK;
 }
 
-// symmetric eigendecomposition, ascending eigenvalues; on exit row j of A is eigenvector j.
-// work: n floats, info: device int.
-int pmd_syevd(pmd_ctx* ctx, int n, float* A, long lda, float* w, float* work, int* info) {
-  pmd_prof_scope prof__(ctx, "rocsolver_ssyevd");
-  PMD_BLAS(ctx, rocsolver_ssyevd(ctx->blas, rocblas_evect_original, rocblas_fill_upper, n, A, (rocblas_int)lda, w, work, info));
-  return PMD_OK;
-}
-
 // ---------------------------------------------------------------- weighted tile bases ------
 // Uw[tile][c][q] = Ut[tile][c][q] * w[q] / cumw[pix[tile][q]] for c < ranks[tile], else 0
 // (decomposition.py:812-816, :847-853).
@@ -340,7 +332,7 @@ int pmd_orthogonalize_impl(pmd_ctx* ctx, float* G, int R, const float* M, int m,
 // Outputs: R_out (rows_p x nk), s_out (nk), Vt_out (nk x n2), nk = min(n1, n2).
 size_t pmd_projected_svd_workspace_bytes_impl(int rows_p, int n1, int n2) {
   const size_t nk = (size_t)std::min(n1, n2);
-  size_t b = nk * nk * sizeof(float) * 2 + nk * (sizeof(float) * 5 + sizeof(int)) + 8192;
+  size_t b = (nk + 4) * nk * sizeof(float) * 2 + nk * (sizeof(float) * 5 + sizeof(int)) + 8192;
   if (n1 > n2) b += (size_t)n1 * n2 * sizeof(float);
   return b + 8192;
 }
@@ -349,7 +341,8 @@ int pmd_projected_svd_impl(pmd_ctx* ctx, const float* P, int rows_p, long ldp, c
                            float* R_out, long ldr, float* s_out, float* Vt_out, long ldvt, void* ws, size_t ws_bytes) {
   const int nk = std::min(n1, n2);
   pmd_arena ar(ws, ws_bytes);
-  float* C = ar.take_n<float>((size_t)nk * nk);
+  const long ldc = pmd_round_up(nk, 4);  // the library's own tridiagonalisation wants 16-byte aligned rows
+  float* C = ar.take_n<float>((size_t)ldc * nk);
   float* Wt = ar.take_n<float>((size_t)nk * nk);
   float* w = ar.take_n<float>(nk);
   float* work = ar.take_n<float>(nk);
@@ -359,9 +352,9 @@ int pmd_projected_svd_impl(pmd_ctx* ctx, const float* P, int rows_p, long ldp, c
   int* info = ar.take_n<int>(4);
   float* left = (n1 > n2) ? ar.take_n<float>((size_t)n1 * n2) : nullptr;
   if (ar.overflow) return pmd_fail(ctx, PMD_ERR_WORKSPACE, "pmd_projected_svd", "workspace too small");
-  if (n1 <= n2) RUN(pmd_gemm_rm(ctx, 0, 1, n1, n1, n2, 1.f, V, ldv, V, ldv, 0.f, C, nk));  // V V^T
-  else RUN(pmd_gemm_rm(ctx, 1, 0, n2, n2, n1, 1.f, V, ldv, V, ldv, 0.f, C, nk));           // V^T V
-  RUN(pmd_syevd(ctx, nk, C, nk, w, work, info));
+  if (n1 <= n2) RUN(pmd_gemm_rm(ctx, 0, 1, n1, n1, n2, 1.f, V, ldv, V, ldv, 0.f, C, ldc));  // V V^T
+  else RUN(pmd_gemm_rm(ctx, 1, 0, n2, n2, n1, 1.f, V, ldv, V, ldv, 0.f, C, ldc));           // V^T V
+  RUN(pmd_syevd(ctx, nk, C, ldc, w, work, info));
   std::vector<float> hw(nk);
   int hinfo = 0;
   PMD_HIP(ctx, hipMemcpyAsync(hw.data(), w, (size_t)nk * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
@@ -383,7 +376,7 @@ int pmd_projected_svd_impl(pmd_ctx* ctx, const float* P, int rows_p, long ldp, c
   PMD_HIP(ctx, hipMemcpyAsync(inv, hinv.data(), (size_t)nk * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
   PMD_HIP(ctx, hipMemcpyAsync(s_out, hs.data(), (size_t)nk * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
   // Wt[c][:] = sign_c * eigenvector perm[c]
-  RUN(launch_gather_rows(ctx, C, nk, perm, sgn, nk, nk, Wt, nk));
+  RUN(launch_gather_rows(ctx, C, ldc, perm, sgn, nk, nk, Wt, nk));
   if (n1 <= n2) {
     // Vt = (W^T V) / s ; R = P W
     RUN(pmd_gemm_rm(ctx, 0, 0, nk, n2, n1, 1.f, Wt, nk, V, ldv, 0.f, Vt_out, ldvt));

@@ -36,6 +36,8 @@ struct pmd_ctx {
   float* tables;  // device: Hann window + FFT twiddles, see prep.hip
   char err[512];
   const char* atx_label;             // profiling name of the next tile_atx launches (NULL: "tile_atx")
+  void* scratch;                     // library-owned device scratch of the eigensolver (sytrd.hip)
+  size_t scratch_bytes;
   bool profile;                      // pmd_profile_enable: HIP events around every kernel group
   std::vector<pmd_prof_rec> recs;
 };

@@ -72,6 +72,7 @@ int pmd_background_rsvd_impl(pmd_ctx* ctx, const float* xs, long D, int n, long 
 int pmd_gemm_rm(pmd_ctx* ctx, int transA, int transB, int m, int n, int k, float alpha, const float* A, long lda,
                 const float* B, long ldb, float beta, float* C, long ldc);
 int pmd_syevd(pmd_ctx* ctx, int n, float* A, long lda, float* w, float* work, int* info);
+int pmd_sytrd_auto(pmd_ctx* ctx, int n, float* A, long lda, float* d, float* e, float* tau, int impl);
 int pmd_launch_weight_tiles(pmd_ctx* ctx, const float* Ut, int dpad, const int* pix, int d, const float* w,
                             const float* cumw, const int* ranks, float* Uw, int n_tiles);
 int pmd_launch_compact_rows(pmd_ctx* ctx, const float* Out, long tile_stride, long ldo, const int* col_off,

@@ -1,0 +1,577 @@
+// Dense symmetric eigensolver for the global stage (decomposition.py:984, :1090, :1129: the
+// jnp.linalg.svd(..., hermitian=True) calls on min(R, frames)-sized Gram matrices).
+//
+//   A = Q T Q^T   blocked Householder tridiagonalisation, hand-written (this file)
+//   T = Z L Z^T   rocSOLVER sstedc (divide and conquer)
+//   E = Q Z       rocSOLVER sormtr
+//
+// The tridiagonalisation is the memory-bound part: every column needs y = A_trailing v over the
+// not-yet-reduced block.  rocSOLVER's ssytrd reads the full square for it and spends five
+// launches per column (~0.55 s at n = 10^4); here the product reads only one triangle (each
+// element a_cr feeds y_c and y_r), and a column costs two launches:
+//   sytrd_advance : finish w of the previous column from the partial sums, apply the panel's
+//                   rank-2 corrections to the next column, partial norms for its reflector
+//   sytrd_symv    : reflector scalars, triangle matrix-vector product tiles, panel dot products
+// followed per 64-column panel by one rank-2k update of the trailing block (rocBLAS ssyr2k).
+// All partial sums are combined in a fixed order: results are run-to-run reproducible.
+//
+// Conventions = LAPACK ssytrd('L') on the column-major view of the buffer.  In memory terms:
+// row c of the buffer holds A(r, c) for r >= c at offset r ("memory-upper" triangle is the one
+// that is read); reflector j is v = [1, A[j][j+2..n)] acting on positions j+1..n-1, tau[j].
+#include "pmd_internal.h"
+#include <rocsolver/rocsolver.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <vector>
+
+#define PMD_BLAS(ctx, call)                                                     \
+  do {                                                                          \
+    rocblas_status s__ = (call);                                                \
+    if (s__ != rocblas_status_success) return pmd_fail(ctx, PMD_ERR_BLAS, #call, rocblas_status_to_string(s__)); \
+  } while (0)
+
+namespace {
+
+constexpr int NB = 64;      // panel width
+constexpr int BR = 64;      // rows of one symv tile
+constexpr int CW = 1024;    // positions of one symv tile (4 waves x 64 lanes x float4)
+constexpr int DCH = 256;    // positions per dot-product workgroup
+
+struct sytrd_bufs {
+  float* W;     // NB x ldw: w vectors of the current panel
+  long ldw;
+  float* RP;    // [chunk q][row c]: row partial sums of the symv tiles
+  float* CP;    // [row block b][position r]: column partial sums
+  long ldp;
+  float* SP;    // per tile workgroup: partial v^T A v
+  float* DP;    // [dot chunk][2][NB]: partial W_k^T v, V_k^T v
+  double* NP;   // per advance workgroup: partial sum of squares
+  float* scal;  // beta, tau, scale of the current reflector
+};
+
+__device__ __forceinline__ int tile_r0(int cs, int b) { return (cs + b * BR) & ~3; }
+__device__ __forceinline__ int tile_nq(int n, int cs, int b) { return (n - tile_r0(cs, b) + CW - 1) / CW; }
+
+// deterministic sum over the workgroup (nthreads <= 512); every thread gets the result
+template <typename T>
+__device__ __forceinline__ T block_sum(T val, T* s_red, int nthreads) {
+  const int tid = threadIdx.x;
+  __syncthreads();
+  s_red[tid] = val;
+  __syncthreads();
+  for (int o = 256; o > 0; o >>= 1) {
+    if (tid < o && tid + o < nthreads) s_red[tid] += s_red[tid + o];
+    __syncthreads();
+  }
+  return s_red[0];
+}
+
+// sum of p[idx * stride] for idx = first, first + step, ... < count, in that order; the first U loads
+// are issued together (straight-line code, so that independent batches of one kernel overlap)
+template <int U>
+__device__ __forceinline__ float batch_sum(const float* __restrict__ p, long stride, int first, int step, int count) {
+  float acc = 0.f;
+  {
+    float t[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = first + u * step;
+      t[u] = p[(long)((idx < count) ? idx : 0) * stride];  // unconditional load: no branch, no wait between loads
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc += (first + u * step < count) ? t[u] : 0.f;
+  }
+  for (int base = first + U * step; base < count; base += U * step) {
+    float t[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = base + u * step;
+      t[u] = p[(long)((idx < count) ? idx : 0) * stride];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc += (base + u * step < count) ? t[u] : 0.f;
+  }
+  return acc;
+}
+
+// ------------------------------------------------------------------------------------------
+// FIN: finish w of column jp = j - 1 (slatrd steps after the symv):
+//        w_pre = A v - V (W^T v) - W (V^T v);  w = tau w_pre - (tau^2/2)(w_pre^T v) v
+// UPD: column j of the panel gets the rank-2 corrections of the i = j - j0 earlier panel columns.
+// Always (unless FIN && !UPD): d[j] and the partial norms of A[j][j+2..n).
+// One workgroup = 64 positions r = j + 64 blockIdx.x + lane; wave `part` of waves 0..3 sums every
+// fourth partial of those positions, so that all loads of a thread are in flight at once.  Lanes
+// 0..3 of wave 4 do the same for position j: w_jp[j] is a scalar every workgroup needs, and it
+// comes out bit-identical to what the owner of that position stores.
+// ------------------------------------------------------------------------------------------
+constexpr int APOS = 64;
+
+template <bool FIN, bool UPD>
+__global__ __launch_bounds__(320) void sytrd_advance_kernel(float* __restrict__ A, long ld, int n, int j, int j0,
+                                                            sytrd_bufs B, int nsp, float* __restrict__ d) {
+  __shared__ float s_dW[NB], s_dV[NB], s_Wj[NB], s_Vj[NB];
+  __shared__ float s_y[4][APOS + 1], s_u[4][APOS + 1];
+  __shared__ float s_red[8];
+  __shared__ float s_sp[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int jp = j - 1;
+  const int ip = jp - j0;  // earlier panel columns seen by column jp
+  int part = wave, slot = lane, r = j + blockIdx.x * APOS + lane;
+  if (wave == 4) {
+    part = lane & 3;
+    slot = APOS;
+    r = (FIN && UPD && lane < 4) ? j : n;
+  }
+  const bool live = r < n;
+  if (!live) r = n - 1;  // idle lanes run the same loads on a valid position and store nothing
+  const bool combiner = live && part == 0;          // wave 0, and lane 0 of wave 4
+  const bool owner = live && wave == 0;             // stores results of position r
+  float tau = 0.f, scale = 0.f, alpha = 0.f;
+  float ypart = 0.f, upart = 0.f, xv = 0.f;
+  float vkv[16], wkv[16];
+  // every load below is unconditional (clamped index + select): the compiler turns a guarded load into a
+  // branch with a full wait behind it, which serialises the ~80 independent loads of a thread
+  const float xj = A[(long)j * ld + r];
+  if (FIN) {
+    {
+      const int cs = j;  // first row of the symv launch of column jp
+      const int nbk = (n - cs + BR - 1) / BR;
+      const int bc = (r - cs) / BR;
+      const int nq = tile_nq(n, cs, bc);
+      int bmax = bc;
+      if (bc + 1 < nbk && tile_r0(cs, bc + 1) <= r) bmax = bc + 1;
+      ypart = batch_sum<3>(B.RP + r, B.ldp, part, 4, nq) + batch_sum<40>(B.CP + r, B.ldp, part, 4, bmax + 1);
+      xv = A[(long)jp * ld + r];
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int k = part + 4 * t;
+        const int kc = (k < ip) ? k : 0;
+        vkv[t] = A[(long)(j0 + kc) * ld + r];
+        wkv[t] = B.W[(long)kc * B.ldw + r];
+      }
+    }
+    tau = B.scal[1];
+    scale = B.scal[2];
+    const int ndch = (n - j + DCH - 1) / DCH;  // dot chunks of the symv launch of column jp (cs = j)
+    if (tid < 2 * NB) {
+      const int k = tid & (NB - 1), which = tid >> 6;
+      const int kc = (k < ip) ? k : 0;
+      float acc = batch_sum<40>(B.DP + (long)which * NB + kc, 2 * NB, 0, 1, ndch);
+      if (k >= ip) acc = 0.f;
+      const float side = UPD ? (which == 0 ? B.W[(long)kc * B.ldw + j] : A[(long)(j0 + kc) * ld + j]) : 0.f;
+      if (which == 0) {
+        s_dW[k] = acc;
+        s_Wj[k] = side;
+      } else {
+        s_dV[k] = acc;
+        s_Vj[k] = side;
+      }
+    }
+    float part_sp = batch_sum<4>(B.SP, 1, tid, 320, nsp);
+    for (int o = 32; o > 0; o >>= 1) part_sp += __shfl_xor(part_sp, o);
+    if (lane == 0) s_red[wave] = part_sp;
+    __syncthreads();
+    const float vav = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) + s_red[4];
+    float cross = 0.f;
+    for (int k = 0; k < ip; ++k) cross += s_dV[k] * s_dW[k];
+    const float vtw = vav - 2.f * cross;
+    alpha = -0.5f * tau * tau * vtw;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int k = part + 4 * t;
+      if (k < ip) {
+        ypart -= vkv[t] * s_dW[k] + wkv[t] * s_dV[k];
+        if (UPD) upart += vkv[t] * s_Wj[k] + wkv[t] * s_Vj[k];
+      }
+    }
+    if (live) {
+      s_y[part][slot] = ypart;
+      if (UPD) s_u[part][slot] = upart;
+    }
+    __syncthreads();
+  }
+  float w = 0.f, v = 0.f, u = 0.f;
+  if (FIN && combiner) {
+    const float y = (s_y[0][slot] + s_y[1][slot]) + (s_y[2][slot] + s_y[3][slot]);
+    if (UPD) u = (s_u[0][slot] + s_u[1][slot]) + (s_u[2][slot] + s_u[3][slot]);
+    v = (r == j) ? 1.f : xv * scale;
+    w = tau * y + alpha * v;
+    if (owner) {
+      B.W[(long)ip * B.ldw + r] = w;
+      A[(long)jp * ld + r] = v;
+    } else {
+      s_sp[0] = w;
+    }
+  }
+  if (FIN && !UPD) return;
+  if (FIN && UPD) __syncthreads();
+  if (wave != 0) return;
+  double sq = 0.0;
+  if (owner) {
+    float x = xj;
+    if (UPD) {
+      x -= u + (v * s_sp[0] + w);
+      A[(long)j * ld + r] = x;
+    }
+    if (r == j) d[j] = x;
+    if (r >= j + 2) sq = (double)x * (double)x;
+  }
+  for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+  if (lane == 0) B.NP[blockIdx.x] = sq;
+}
+
+// ------------------------------------------------------------------------------------------
+// Column j: reflector scalars from the partial norms (every workgroup, same order), then
+//   tiles (b, q): rows c in [cs + 64 b, +64), positions [r0(b) + 1024 q, +1024), cs = j + 1:
+//       RP[q][c]  = sum_{r in tile, r >= c} A[c][r] v[r]
+//       CP[b][r]  = sum_{c in tile, c <  r} A[c][r] v[c]
+//   dot workgroups: W_k^T v and V_k^T v over 256 positions for the k < j - j0 panel columns.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void sytrd_symv_kernel(const float* __restrict__ A, long ld, int n, int j, int j0,
+                                                         sytrd_bufs B, int n_np, int npairs, int nbk,
+                                                         float* __restrict__ e, float* __restrict__ tau_out) {
+  __shared__ float s_v[BR];
+  __shared__ float s_row[4][BR];
+  __shared__ float s_col[4][64][4];
+  __shared__ float s_red[8];
+  __shared__ float s_sc[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wc = wave & 3, rh = wave >> 2;  // position group and row half of this wave
+  const int cs = j + 1;
+  const float* xr = A + (long)j * ld;
+  const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+  const bool is_dot = (int)blockIdx.y >= npairs;
+
+  // ---- which tile: row blocks are paired (p, nbk-1-p) so that every grid row has about the same work
+  int b = blockIdx.y, q = blockIdx.x;
+  bool valid = !is_dot;
+  if (valid) {
+    const int nq_b = tile_nq(n, cs, b);
+    if (q >= nq_b) {
+      const int b2 = nbk - 1 - b;
+      q -= nq_b;
+      if (b2 == b || q >= tile_nq(n, cs, b2)) valid = false;
+      b = b2;
+    }
+  }
+  if (!valid && !is_dot) {
+    if (tid == 0) B.SP[wg] = 0.f;
+    return;
+  }
+  const int cb = is_dot ? cs : cs + b * BR;
+  const int rows = min(BR, n - cb);
+  const int r0 = tile_r0(cs, is_dot ? 0 : b);
+  const int pos = r0 + (is_dot ? 0 : q) * CW + wc * 256 + lane * 4;
+  const int n4 = (n + 3) & ~3;
+  const bool ok = pos < n4;
+  // Every load of the tile is issued before anything waits: one memory round trip per workgroup.  The
+  // loads are unconditional (clamped row / position, results masked later): a guarded load becomes a
+  // branch with a full wait behind it.  Rows >= rows repeat the last row and meet v = 0.
+  float4 a[32];
+  float v4[4];
+  {
+    const int posc = ok ? pos : r0;
+    const float* ap = A + (long)cb * ld + posc;
+#pragma unroll
+    for (int uu = 0; uu < 32; ++uu) a[uu] = *reinterpret_cast<const float4*>(ap + (long)min(rh * 32 + uu, rows - 1) * ld);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int r = pos + t;
+      const bool in = r < n && r > cs;
+      v4[t] = xr[in ? r : cs];
+      if (!in) v4[t] = 0.f;
+    }
+    if (tid < BR) {
+      const int c = cb + tid;
+      const bool in = c < n && c > cs;
+      const float xc = xr[in ? c : cs];
+      s_v[tid] = in ? xc : 0.f;
+    }
+  }
+  if (wave == 0) {
+    // reflector scalars: fixed-order tree over the partial norms, every lane of wave 0 holds the result
+    double xn = 0.0;
+    for (int t = lane; t < n_np; t += 64) xn += B.NP[t];
+    for (int o = 32; o > 0; o >>= 1) xn += __shfl_xor(xn, o);
+    const float a0 = xr[cs];
+    float beta = a0, tau = 0.f, scale = 0.f;
+    if (xn > 0.0) {
+      const double nr = sqrt((double)a0 * (double)a0 + xn);
+      const double bt = (a0 >= 0.f) ? -nr : nr;
+      beta = (float)bt;
+      tau = (float)((bt - (double)a0) / bt);
+      scale = (float)(1.0 / ((double)a0 - bt));
+    }
+    if (lane == 0) {
+      s_sc[0] = beta;
+      s_sc[1] = tau;
+      s_sc[2] = scale;
+      if (blockIdx.x == 0 && blockIdx.y == 0) {
+        e[j] = beta;
+        tau_out[j] = tau;
+        B.scal[0] = beta;
+        B.scal[1] = tau;
+        B.scal[2] = scale;
+      }
+    }
+  }
+  __syncthreads();
+  const float scale = s_sc[2];
+
+  if (is_dot) {
+    // ---- panel dot products
+    const int i = j - j0;
+    const int dchunk = ((int)blockIdx.y - npairs) * gridDim.x + blockIdx.x;
+    const int base = cs + dchunk * DCH;
+    if (base >= n || i == 0) return;
+    float vv[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int r = base + g * 64 + lane;
+      const float xg = xr[min(r, n - 1)];
+      vv[g] = (r < n) ? ((r == cs) ? 1.f : xg * scale) : 0.f;
+    }
+    for (int k = wave; k < i; k += 8) {
+      float aw = 0.f, av = 0.f;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int r = min(base + g * 64 + lane, n - 1);  // beyond n: vv = 0
+        aw += B.W[(long)k * B.ldw + r] * vv[g];
+        av += A[(long)(j0 + k) * ld + r] * vv[g];
+      }
+      for (int o = 32; o > 0; o >>= 1) {
+        aw += __shfl_xor(aw, o);
+        av += __shfl_xor(av, o);
+      }
+      if (lane == 0) {
+        B.DP[((long)dchunk * 2 + 0) * NB + k] = aw;
+        B.DP[((long)dchunk * 2 + 1) * NB + k] = av;
+      }
+    }
+    return;
+  }
+  // v = x * scale, v[cs] = 1
+#pragma unroll
+  for (int t = 0; t < 4; ++t) v4[t] = (pos + t == cs) ? 1.f : v4[t] * scale;
+  if (tid < BR) s_v[tid] = (cb + tid == cs) ? 1.f : s_v[tid] * scale;
+  __syncthreads();
+
+  const bool edge = (q == 0) || (r0 + (q + 1) * CW > n);
+  float col[4] = {0.f, 0.f, 0.f, 0.f};
+  float pr[32];
+  if (edge) {
+#pragma unroll
+    for (int uu = 0; uu < 32; ++uu) {
+      const int c = cb + rh * 32 + uu;
+      const float vc = s_v[rh * 32 + uu];
+      // row part uses r >= c, column part r > c; nothing beyond n
+      const float m0 = (pos + 0 < n) ? a[uu].x : 0.f, m1 = (pos + 1 < n) ? a[uu].y : 0.f,
+                  m2 = (pos + 2 < n) ? a[uu].z : 0.f, m3 = (pos + 3 < n) ? a[uu].w : 0.f;
+      pr[uu] = (((pos + 0 >= c) ? m0 * v4[0] : 0.f) + ((pos + 1 >= c) ? m1 * v4[1] : 0.f)) +
+               (((pos + 2 >= c) ? m2 * v4[2] : 0.f) + ((pos + 3 >= c) ? m3 * v4[3] : 0.f));
+      col[0] += (pos + 0 > c) ? m0 * vc : 0.f;
+      col[1] += (pos + 1 > c) ? m1 * vc : 0.f;
+      col[2] += (pos + 2 > c) ? m2 * vc : 0.f;
+      col[3] += (pos + 3 > c) ? m3 * vc : 0.f;
+    }
+  } else {
+#pragma unroll
+    for (int uu = 0; uu < 32; ++uu) {
+      const float vc = s_v[rh * 32 + uu];
+      pr[uu] = (a[uu].x * v4[0] + a[uu].y * v4[1]) + (a[uu].z * v4[2] + a[uu].w * v4[3]);
+      col[0] += a[uu].x * vc;
+      col[1] += a[uu].y * vc;
+      col[2] += a[uu].z * vc;
+      col[3] += a[uu].w * vc;
+    }
+  }
+  // 32 row sums across the 64 lanes: halve the number of values per lane at every exchange
+#pragma unroll
+  for (int s = 0; s < 5; ++s) {
+    const int off = 32 >> s, half = 16 >> s;
+    const bool upper = (lane & off) != 0;
+#pragma unroll
+    for (int t = 0; t < half; ++t) {
+      const float send = upper ? pr[t] : pr[t + half];
+      const float keep = upper ? pr[t + half] : pr[t];
+      pr[t] = keep + __shfl_xor(send, off);
+    }
+  }
+  pr[0] += __shfl_xor(pr[0], 1);
+  if ((lane & 1) == 0) s_row[wc][rh * 32 + (lane >> 1)] = pr[0];
+  if (rh == 1) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) s_col[wc][lane][t] = col[t];
+  }
+  __syncthreads();
+  float spart = 0.f;
+  if (tid < rows) {
+    const float rs = (s_row[0][tid] + s_row[1][tid]) + (s_row[2][tid] + s_row[3][tid]);
+    B.RP[(long)q * B.ldp + cb + tid] = rs;
+    spart = s_v[tid] * rs;
+  }
+  if (rh == 0) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) col[t] += s_col[wc][lane][t];
+    spart += (v4[0] * col[0] + v4[1] * col[1]) + (v4[2] * col[2] + v4[3] * col[3]);
+    if (ok) *reinterpret_cast<float4*>(B.CP + (long)b * B.ldp + pos) = make_float4(col[0], col[1], col[2], col[3]);
+  }
+  for (int o = 32; o > 0; o >>= 1) spart += __shfl_xor(spart, o);
+  if (lane == 0) s_red[wave] = spart;
+  __syncthreads();
+  if (tid == 0) {
+    float tot = 0.f;
+    for (int t = 0; t < 8; ++t) tot += s_red[t];
+    B.SP[wg] = tot;
+  }
+}
+
+__global__ void copy_rows_kernel(const float* __restrict__ src, long lds_, float* __restrict__ dst, long ldd, int n) {
+  const int row = blockIdx.y;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x)
+    dst[(long)row * ldd + c] = src[(long)row * lds_ + c];
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+size_t pmd_sytrd_workspace_bytes_impl(int n) {
+  const size_t n4 = (size_t)pmd_round_up(n, 4);
+  const size_t nq = (size_t)(n / CW + 2), nbk = (size_t)(n / BR + 2);
+  size_t b = 0;
+  b += NB * n4 * sizeof(float) + 256;                 // W
+  b += nq * n4 * sizeof(float) + 256;                 // RP
+  b += nbk * n4 * sizeof(float) + 256;                // CP
+  b += (nq + 2) * (nbk + 2) * sizeof(float) + 256;    // SP
+  b += (size_t)(n / DCH + 2) * 2 * NB * sizeof(float) + 256;  // DP
+  b += (size_t)(n / APOS + 2) * sizeof(double) + 256;  // NP
+  b += 4096;
+  return b;
+}
+
+// Tridiagonalise the symmetric matrix held in A (memory-upper triangle read, see the header comment).
+// d[n], e[n-1], tau[n-1] on the device.  lda % 4 == 0, lda >= round_up(n, 4), A 16-byte aligned.
+int pmd_sytrd_impl(pmd_ctx* ctx, int n, float* A, long lda, float* d, float* e, float* tau, void* ws, size_t ws_bytes) {
+  pmd_prof_scope prof__(ctx, "sytrd");
+  if (n < 1) return PMD_OK;
+  const long n4 = pmd_round_up(n, 4);
+  if (lda % 4 != 0 || lda < n4 || ((uintptr_t)A & 15)) return pmd_fail(ctx, PMD_ERR_ARG, "pmd_sytrd", "lda must be a multiple of 4, >= round_up(n,4), A 16-byte aligned");
+  pmd_arena ar(ws, ws_bytes);
+  sytrd_bufs B;
+  const size_t nqmax = (size_t)(n / CW + 2), nbkmax = (size_t)(n / BR + 2);
+  B.ldw = n4;
+  B.ldp = n4;
+  B.W = ar.take_n<float>(NB * (size_t)n4);
+  B.RP = ar.take_n<float>(nqmax * n4);
+  B.CP = ar.take_n<float>(nbkmax * n4);
+  B.SP = ar.take_n<float>((nqmax + 2) * (nbkmax + 2));
+  B.DP = ar.take_n<float>((size_t)(n / DCH + 2) * 2 * NB);
+  B.NP = ar.take_n<double>((size_t)(n / APOS + 2));
+  B.scal = ar.take_n<float>(16);
+  if (ar.overflow) return pmd_fail(ctx, PMD_ERR_WORKSPACE, "pmd_sytrd", "workspace too small");
+  hipStream_t st = ctx->stream;
+  const float one = 1.f, minus1 = -1.f;
+  int nsp = 0;
+  for (int j0 = 0; j0 < n - 1; j0 += NB) {
+    const int nbc = std::min(NB, n - 1 - j0);
+    for (int i = 0; i < nbc; ++i) {
+      const int j = j0 + i;
+      const int ga = (n - j + APOS - 1) / APOS;
+      if (i == 0)
+        hipLaunchKernelGGL((sytrd_advance_kernel<false, false>), dim3(ga), dim3(320), 0, st, A, lda, n, j, j0, B, nsp, d);
+      else
+        hipLaunchKernelGGL((sytrd_advance_kernel<true, true>), dim3(ga), dim3(320), 0, st, A, lda, n, j, j0, B, nsp, d);
+      const int cs = j + 1;
+      const int nbk = (n - cs + BR - 1) / BR;
+      const int npairs = (nbk + 1) / 2;
+      auto r0 = [&](int b) { return (cs + b * BR) & ~3; };
+      auto nq = [&](int b) { return (n - r0(b) + CW - 1) / CW; };
+      int nqx = 1;
+      for (int p = 0; p < npairs; ++p) nqx = std::max(nqx, nq(p) + ((nbk - 1 - p != p) ? nq(nbk - 1 - p) : 0));
+      const int ndch = (i > 0) ? (n - cs + DCH - 1) / DCH : 0;
+      const int drows = (ndch + nqx - 1) / nqx;
+      hipLaunchKernelGGL(sytrd_symv_kernel, dim3(nqx, npairs + drows), dim3(512), 0, st, A, lda, n, j, j0, B, ga, npairs, nbk, e, tau);
+      nsp = nqx * npairs;
+    }
+    PMD_LAUNCH_CHECK(ctx, "sytrd panel");
+    const int ts = j0 + nbc;
+    hipLaunchKernelGGL((sytrd_advance_kernel<true, false>), dim3((n - ts + APOS - 1) / APOS), dim3(320), 0, st, A, lda, n, ts, j0, B, nsp, d);
+    PMD_LAUNCH_CHECK(ctx, "sytrd_advance_kernel");
+    PMD_BLAS(ctx, rocblas_ssyr2k(ctx->blas, rocblas_fill_lower, rocblas_operation_none, n - ts, nbc, &minus1,
+                                 A + (long)j0 * lda + ts, (rocblas_int)lda, B.W + ts, (rocblas_int)B.ldw, &one,
+                                 A + (long)ts * lda + ts, (rocblas_int)lda));
+  }
+  hipLaunchKernelGGL((sytrd_advance_kernel<false, false>), dim3(1), dim3(320), 0, st, A, lda, n, n - 1, n - 1, B, 0, d);
+  PMD_LAUNCH_CHECK(ctx, "sytrd_advance_kernel");
+  return PMD_OK;
+}
+
+// rocSOLVER's own tridiagonalisation with the same conventions (tests, small matrices)
+int pmd_sytrd_rocsolver(pmd_ctx* ctx, int n, float* A, long lda, float* d, float* e, float* tau) {
+  pmd_prof_scope prof__(ctx, "rocsolver_ssytrd");
+  PMD_BLAS(ctx, rocsolver_ssytrd(ctx->blas, rocblas_fill_lower, n, A, (rocblas_int)lda, d, e, tau));
+  return PMD_OK;
+}
+
+// Library-owned scratch of the eigensolver (grown on demand, released with the context)
+static int ctx_scratch(pmd_ctx* ctx, size_t bytes, void** out) {
+  if (ctx->scratch_bytes < bytes) {
+    PMD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    ctx->scratch = nullptr;
+    ctx->scratch_bytes = 0;
+    PMD_HIP(ctx, hipMalloc(&ctx->scratch, bytes));
+    ctx->scratch_bytes = bytes;
+  }
+  *out = ctx->scratch;
+  return PMD_OK;
+}
+
+// Tridiagonalisation alone (tests and probes): impl 0 = rocSOLVER ssytrd('L'), 1 = this file.
+int pmd_sytrd_auto(pmd_ctx* ctx, int n, float* A, long lda, float* d, float* e, float* tau, int impl) {
+  if (impl == 0) return pmd_sytrd_rocsolver(ctx, n, A, lda, d, e, tau);
+  const size_t tb = pmd_sytrd_workspace_bytes_impl(n);
+  void* scratch = nullptr;
+  int rc = ctx_scratch(ctx, tb, &scratch);
+  if (rc != PMD_OK) return rc;
+  return pmd_sytrd_impl(ctx, n, A, lda, d, e, tau, scratch, tb);
+}
+
+// Symmetric eigendecomposition, ascending eigenvalues; on exit memory row j of A is eigenvector j.
+// A must hold the full symmetric matrix.  work: n floats, info: device int.
+int pmd_syevd(pmd_ctx* ctx, int n, float* A, long lda, float* w, float* work, int* info) {
+  const char* mode = getenv("PMD_SYEVD");
+  const bool force_lib = mode && !strcmp(mode, "rocsolver");
+  const bool force_own = mode && !strcmp(mode, "own");
+  const bool own = !force_lib && (force_own || n >= 1024) && n >= 3 && lda % 4 == 0 && lda >= pmd_round_up(n, 4) && !((uintptr_t)A & 15);
+  if (!own) {
+    pmd_prof_scope prof__(ctx, "rocsolver_ssyevd");
+    PMD_BLAS(ctx, rocsolver_ssyevd(ctx->blas, rocblas_evect_original, rocblas_fill_upper, n, A, (rocblas_int)lda, w, work, info));
+    return PMD_OK;
+  }
+  const size_t tb = pmd_sytrd_workspace_bytes_impl(n);
+  const size_t zb = (size_t)n * n * sizeof(float);
+  void* scratch = nullptr;
+  int rc = ctx_scratch(ctx, tb + zb + 2 * (size_t)n * sizeof(float) + 1024, &scratch);
+  if (rc != PMD_OK) return rc;
+  pmd_arena ar(scratch, ctx->scratch_bytes);
+  float* Z = ar.take_n<float>((size_t)n * n);
+  float* e = ar.take_n<float>(n);
+  float* tau = ar.take_n<float>(n);
+  void* tws = ar.take(tb);
+  rc = pmd_sytrd_impl(ctx, n, A, lda, w, e, tau, tws, tb);
+  if (rc != PMD_OK) return rc;
+  {
+    pmd_prof_scope prof__(ctx, "rocsolver_sstedc");
+    PMD_BLAS(ctx, rocsolver_sstedc(ctx->blas, rocblas_evect_tridiagonal, n, w, e, Z, n, info));
+  }
+  {
+    pmd_prof_scope prof__(ctx, "rocsolver_sormtr");
+    PMD_BLAS(ctx, rocsolver_sormtr(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, n, n, A,
+                                   (rocblas_int)lda, tau, Z, n));
+  }
+  hipLaunchKernelGGL(copy_rows_kernel, dim3(8, n), dim3(256), 0, ctx->stream, Z, (long)n, A, lda, n);
+  PMD_LAUNCH_CHECK(ctx, "copy_rows_kernel");
+  return PMD_OK;
+}

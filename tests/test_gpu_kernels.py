@@ -314,3 +314,101 @@ def test_syevd_and_gemm(gpu_ctx):
     ctx.call("pmd_gemm", 0, 1, 70, 70, 50, 1.0, P(Bd), 50, P(Bd), 50, 0.0, P(out2), 70)
     ctx.sync()
     np.testing.assert_allclose(out2.cpu().numpy(), Bm @ Bm.T, rtol=1e-4, atol=1e-4)
+
+
+def _sym_matrix(rng, n):
+    A = rng.standard_normal((n, n)).astype(np.float32)
+    S = A @ A.T / np.float32(n) + np.diag(rng.standard_normal(n).astype(np.float32) * 3)
+    S = 0.5 * (S + S.T)
+    return S.astype(np.float32)
+
+
+def _run_sytrd(ctx, S, impl):
+    torch = _t()
+    n = S.shape[0]
+    ld = (n + 3) // 4 * 4
+    buf = np.full((n, ld), np.nan, dtype=np.float32)  # the padding must never be read into a result
+    buf[:, :n] = S
+    Ad = dev(ctx, buf)
+    d = torch.zeros(n, dtype=torch.float32, device=ctx.device)
+    e = torch.zeros(n, dtype=torch.float32, device=ctx.device)
+    tau = torch.zeros(n, dtype=torch.float32, device=ctx.device)
+    ctx.call("pmdk_sytrd", n, P(Ad), ld, P(d), P(e), P(tau), impl)
+    ctx.sync()
+    return Ad.cpu().numpy()[:, :n], d.cpu().numpy(), e.cpu().numpy()[:n - 1], tau.cpu().numpy()[:n - 1]
+
+
+@pytest.mark.parametrize("n", [3, 5, 67, 300, 1030])
+def test_sytrd_own_kernels_reconstruct(gpu_ctx, n):
+    """A = Q T Q^T with Q rebuilt on the host (fp64) from the stored reflectors (LAPACK ssytrd('L') layout)."""
+    from scipy.linalg import eigvalsh_tridiagonal
+
+    rng = np.random.default_rng(n)
+    S = _sym_matrix(rng, n)
+    Am, d, e, tau = _run_sytrd(gpu_ctx, S, 1)
+    assert np.all(np.isfinite(d)) and np.all(np.isfinite(e)) and np.all(np.isfinite(tau))
+    Q = np.eye(n)
+    for j in range(n - 2, -1, -1):
+        v = np.zeros(n)
+        v[j + 1] = 1.0
+        v[j + 2:] = Am[j, j + 2:]
+        Q -= tau[j] * np.outer(v, v @ Q)
+    Tm = np.diag(d.astype(np.float64)) + np.diag(e.astype(np.float64), 1) + np.diag(e.astype(np.float64), -1)
+    S64 = S.astype(np.float64)
+    scale = np.abs(S64).max() * np.sqrt(n)
+    assert np.abs(Q.T @ Q - np.eye(n)).max() < 2e-5 * np.sqrt(n)
+    assert np.abs(Q.T @ S64 @ Q - Tm).max() < 3e-6 * scale
+    ev = eigvalsh_tridiagonal(d.astype(np.float64), e.astype(np.float64))
+    np.testing.assert_allclose(ev, np.linalg.eigvalsh(S64), atol=3e-6 * scale)
+    if n == 67:
+        # same conventions as rocSOLVER's ssytrd: the tridiagonal matrices agree entry by entry
+        _, d0, e0, tau0 = _run_sytrd(gpu_ctx, S, 0)
+        np.testing.assert_allclose(d, d0, atol=2e-4 * np.abs(d0).max())
+        np.testing.assert_allclose(e, e0, atol=2e-4 * np.abs(d0).max())
+        np.testing.assert_allclose(tau, tau0, atol=2e-4)
+
+
+def test_sytrd_eigenvalues_2500(gpu_ctx):
+    from scipy.linalg import eigvalsh_tridiagonal
+
+    n = 2500
+    rng = np.random.default_rng(1)
+    S = _sym_matrix(rng, n)
+    _, d, e, tau = _run_sytrd(gpu_ctx, S, 1)
+    ev = eigvalsh_tridiagonal(d.astype(np.float64), e.astype(np.float64))
+    ref = np.linalg.eigvalsh(S.astype(np.float64))
+    np.testing.assert_allclose(ev, ref, atol=3e-6 * np.abs(S).max() * np.sqrt(n))
+    _, d2, e2, _ = _run_sytrd(gpu_ctx, S, 1)
+    np.testing.assert_array_equal(d, d2)  # fixed summation order: bitwise reproducible
+    np.testing.assert_array_equal(e, e2)
+
+
+@pytest.mark.parametrize("n,force", [(301, True), (1200, False)])
+def test_syevd_own_path(gpu_ctx, n, force, monkeypatch):
+    torch = _t()
+    ctx = gpu_ctx
+    if force:
+        monkeypatch.setenv("PMD_SYEVD", "own")
+    rng = np.random.default_rng(n)
+    S = _sym_matrix(rng, n)
+    ld = (n + 3) // 4 * 4
+    buf = np.zeros((n, ld), dtype=np.float32)
+    buf[:, :n] = S
+    Sd = dev(ctx, buf)
+    w = torch.empty(n, dtype=torch.float32, device=ctx.device)
+    work = torch.empty(n, dtype=torch.float32, device=ctx.device)
+    info = torch.zeros(4, dtype=torch.int32, device=ctx.device)
+    ctx.profile_enable(True)
+    ctx.call("pmdk_syevd", n, P(Sd), ld, P(w), P(work), P(info))
+    ctx.sync()
+    prof = ctx.profile_summary()
+    ctx.profile_enable(False)
+    assert "sytrd" in prof, prof  # the library's own tridiagonalisation ran
+    assert int(info[0]) == 0
+    wv = w.cpu().numpy().astype(np.float64)
+    E = Sd.cpu().numpy()[:, :n].astype(np.float64)  # rows are eigenvectors
+    S64 = S.astype(np.float64)
+    assert np.all(np.diff(wv) >= 0)
+    np.testing.assert_allclose(wv, np.linalg.eigvalsh(S64), atol=3e-6 * np.abs(S64).max() * np.sqrt(n))
+    assert np.abs(E @ E.T - np.eye(n)).max() < 5e-5 * np.sqrt(n)
+    assert np.abs(E @ S64 - wv[:, None] * E).max() < 1e-5 * np.abs(S64).max() * np.sqrt(n)
