@@ -164,7 +164,9 @@ size_t pmd_orthogonalize_chol_workspace_bytes(int Rc, int m);
 size_t pmd_projected_svd_factored_workspace_bytes(int Rc, int m, int rp, int T);
 int pmd_projected_svd_factored(pmd_ctx* ctx, const float* M, int Rc, int m, long ldm, const float* Et, int rp, long lde,
                                const float* Z, int T, long ldz, float* R_out, long ldr, float* s_out, float* Vt_out,
-                               long ldvt, float* Vp_out, long ldvp, void* ws, size_t ws_bytes);
+                               long ldvt, float* Vp_out, long ldvp, float* X1_out, void* ws, size_t ws_bytes);
+/* (X1_out: optional m x rp, ld rp, receives Et^T W.  With R_out == NULL the last product R = M X1 is left to the
+ * caller, who can then form R in row blocks with pmd_gemm and overlap their download with the next block.) */
 /* A13/A14: CSR arrays of the sparse spatial matrix built on the device (decomposition.py:812-853, :929-930);
  * cover1[d1][4] / cover2[d2][4]: indices of the tile-row / tile-column origins covering each FOV row / column. */
 int pmd_csr_count(pmd_ctx* ctx, int d1, int d2, int order_f, const int* cover1, const int* cover2, int n2,

@@ -781,13 +781,14 @@ size_t pmd_projected_svd_factored_workspace_bytes_impl(int Rc, int m, int rp, in
 // Vp_out (rp x T, optional, may be NULL) receives V = P^T Z.
 int pmd_projected_svd_factored_impl(pmd_ctx* ctx, const float* M, int Rc, int m, long ldm, const float* Et, int rp,
                                     long lde, const float* Z, int T, long ldz, float* R_out, long ldr, float* s_out,
-                                    float* Vt_out, long ldvt, float* Vp_out, long ldvp, void* ws, size_t ws_bytes) {
+                                    float* Vt_out, long ldvt, float* Vp_out, long ldvp, float* X1_out, void* ws,
+                                    size_t ws_bytes) {
   if (rp > T) return pmd_fail(ctx, PMD_ERR_UNSUPPORTED, "pmd_projected_svd_factored", "needs R' <= T");
   pmd_arena ar(ws, ws_bytes);
   float* W1 = ar.take_n<float>((size_t)m * T);
   float* Vp = Vp_out ? Vp_out : ar.take_n<float>((size_t)rp * T);
   const long ldv = Vp_out ? ldvp : T;
-  float* X1 = ar.take_n<float>((size_t)m * rp);
+  float* X1 = X1_out ? X1_out : ar.take_n<float>((size_t)m * rp);
   float* Mt = ar.take_n<float>((size_t)m * Rc);
   const size_t sub_bytes = pmd_projected_svd_workspace_bytes_impl(1, rp, T);
   void* sub = ar.take(sub_bytes);
@@ -803,7 +804,7 @@ int pmd_projected_svd_factored_impl(pmd_ctx* ctx, const float* M, int Rc, int m,
   RUN(pmd_projected_svd_impl(ctx, nullptr, 0, 0, Vp, rp, T, ldv, Wmat, rp, s_out, Vt_out, ldvt, sub, sub_bytes));
   // R = M (Et^T W)
   RUN(pmd_gemm_rm(ctx, 1, 0, m, rp, rp, 1.f, Et, lde, Wmat, rp, 0.f, X1, rp));
-  RUN(pmd_gemm_rm(ctx, 0, 0, Rc, rp, m, 1.f, M, ldm, X1, rp, 0.f, R_out, ldr));
+  if (R_out) RUN(pmd_gemm_rm(ctx, 0, 0, Rc, rp, m, 1.f, M, ldm, X1, rp, 0.f, R_out, ldr));
   return PMD_OK;
 }
 

@@ -110,7 +110,8 @@ size_t pmd_projected_svd_factored_workspace_bytes_impl(int Rc, int m, int rp, in
 size_t pmd_orthogonalize_chol_workspace_bytes_impl(int Rc, int m);
 int pmd_projected_svd_factored_impl(pmd_ctx* ctx, const float* M, int Rc, int m, long ldm, const float* Et, int rp,
                                     long lde, const float* Z, int T, long ldz, float* R_out, long ldr, float* s_out,
-                                    float* Vt_out, long ldvt, float* Vp_out, long ldvp, void* ws, size_t ws_bytes);
+                                    float* Vt_out, long ldvt, float* Vp_out, long ldvp, float* X1_out, void* ws,
+                                    size_t ws_bytes);
 int pmd_orthogonalize_chol_impl(pmd_ctx* ctx, const float* M, int Rc, int m, long ldm, const float* GM, long ldgm,
                                 float* Et_out, long lde, int* ok_host, void* ws, size_t ws_bytes);
 

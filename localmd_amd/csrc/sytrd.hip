@@ -433,7 +433,77 @@ __global__ void copy_rows_kernel(const float* __restrict__ src, long lds_, float
     dst[(long)row * ldd + c] = src[(long)row * lds_ + c];
 }
 
+// Vb[k][r - p0] = reflector k0 + k at position r (0 before its unit entry, 1 at k0 + k + 1); a reflector
+// with tau = 0 is the identity and becomes a zero row
+__global__ void extract_v_kernel(const float* __restrict__ A, long lda, const float* __restrict__ tau, int k0, int p0,
+                                 int np, float* __restrict__ Vb, long ldv) {
+  const int k = blockIdx.y;
+  const int unit = k0 + k + 1;
+  const bool dead = tau[k0 + k] == 0.f;
+  for (int rr = blockIdx.x * blockDim.x + threadIdx.x; rr < np; rr += gridDim.x * blockDim.x) {
+    const int r = p0 + rr;
+    float v = 0.f;
+    if (!dead && r >= unit) v = (r == unit) ? 1.f : A[(long)(k0 + k) * lda + r];
+    Vb[(long)k * ldv + rr] = v;
+  }
+}
+
+// S = Vb Vb^T (row-major kb x kb) -> T^{-1} = striu(S) + diag(1 / tau) in place
+__global__ void tinv_kernel(float* __restrict__ S, int kb, const float* __restrict__ tau, int k0) {
+  const int i = blockIdx.x;
+  for (int jj = threadIdx.x; jj < kb; jj += blockDim.x) {
+    float v = S[(long)i * kb + jj];
+    if (jj < i) v = 0.f;
+    if (jj == i) {
+      const float t = tau[k0 + i];
+      v = (t == 0.f) ? 1.f : 1.f / t;
+    }
+    S[(long)i * kb + jj] = v;
+  }
+}
+
 }  // namespace
+
+// Z <- Q Z for the Q of pmd_sytrd_impl (reflectors in A, tau): memory row m of Z is one vector over the
+// positions.  Blocks of QB reflectors in compact WY form, Q_blk = I - V T V^T with
+// T^{-1} = striu(V^T V) + diag(1/tau), applied last block first:  Z -= ((Z V) T^T) V^T.
+// Three GEMMs and one triangular solve per block (rocSOLVER's sormtr works in 64-column steps at ~20 TFLOP/s).
+constexpr int QB = 256;
+
+size_t pmd_apply_q_workspace_bytes_impl(int n) {
+  return ((size_t)QB * n + (size_t)QB * QB + (size_t)n * QB) * sizeof(float) + 4096;
+}
+
+int pmd_apply_q_impl(pmd_ctx* ctx, int n, const float* A, long lda, const float* tau, float* Z, long ldz, void* ws,
+                     size_t ws_bytes) {
+  pmd_prof_scope prof__(ctx, "apply_q");
+  if (n < 2) return PMD_OK;
+  pmd_arena ar(ws, ws_bytes);
+  float* Vb = ar.take_n<float>((size_t)QB * n);
+  float* S = ar.take_n<float>((size_t)QB * QB);
+  float* Y = ar.take_n<float>((size_t)n * QB);
+  if (ar.overflow) return pmd_fail(ctx, PMD_ERR_WORKSPACE, "pmd_apply_q", "workspace too small");
+  const int nref = n - 1;
+  const float one = 1.f;
+  for (int k0 = (nref - 1) / QB * QB; k0 >= 0; k0 -= QB) {
+    const int kb = std::min(QB, nref - k0);
+    const int p0 = k0 + 1, np = n - p0;
+    hipLaunchKernelGGL(extract_v_kernel, dim3((np + 255) / 256, kb), dim3(256), 0, ctx->stream, A, lda, tau, k0, p0, np, Vb, (long)np);
+    PMD_LAUNCH_CHECK(ctx, "extract_v_kernel");
+    int rc = pmd_gemm_rm(ctx, 0, 1, kb, kb, np, 1.f, Vb, np, Vb, np, 0.f, S, kb);
+    if (rc != PMD_OK) return rc;
+    hipLaunchKernelGGL(tinv_kernel, dim3(kb), dim3(256), 0, ctx->stream, S, kb, tau, k0);
+    PMD_LAUNCH_CHECK(ctx, "tinv_kernel");
+    rc = pmd_gemm_rm(ctx, 0, 1, n, kb, np, 1.f, Z + p0, ldz, Vb, np, 0.f, Y, kb);  // Y = Z V
+    if (rc != PMD_OK) return rc;
+    // X = Y T^T  <=>  T^{-1} X^T = Y^T: the row-major upper triangular T^{-1} is a column-major lower one, transposed
+    PMD_BLAS(ctx, rocblas_strsm(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_transpose,
+                                rocblas_diagonal_non_unit, kb, n, &one, S, kb, Y, kb));
+    rc = pmd_gemm_rm(ctx, 0, 0, n, np, kb, -1.f, Y, kb, Vb, np, 1.f, Z + p0, ldz);  // Z -= X V^T
+    if (rc != PMD_OK) return rc;
+  }
+  return PMD_OK;
+}
 
 // ---------------------------------------------------------------------------------------------
 size_t pmd_sytrd_workspace_bytes_impl(int n) {
@@ -550,10 +620,10 @@ int pmd_syevd(pmd_ctx* ctx, int n, float* A, long lda, float* w, float* work, in
     PMD_BLAS(ctx, rocsolver_ssyevd(ctx->blas, rocblas_evect_original, rocblas_fill_upper, n, A, (rocblas_int)lda, w, work, info));
     return PMD_OK;
   }
-  const size_t tb = pmd_sytrd_workspace_bytes_impl(n);
+  const size_t tb = std::max(pmd_sytrd_workspace_bytes_impl(n), pmd_apply_q_workspace_bytes_impl(n));
   const size_t zb = (size_t)n * n * sizeof(float);
   void* scratch = nullptr;
-  int rc = ctx_scratch(ctx, tb + zb + 2 * (size_t)n * sizeof(float) + 1024, &scratch);
+  int rc = ctx_scratch(ctx, tb + zb + 2 * (size_t)n * sizeof(float) + 4096, &scratch);
   if (rc != PMD_OK) return rc;
   pmd_arena ar(scratch, ctx->scratch_bytes);
   float* Z = ar.take_n<float>((size_t)n * n);
@@ -566,10 +636,14 @@ int pmd_syevd(pmd_ctx* ctx, int n, float* A, long lda, float* w, float* work, in
     pmd_prof_scope prof__(ctx, "rocsolver_sstedc");
     PMD_BLAS(ctx, rocsolver_sstedc(ctx->blas, rocblas_evect_tridiagonal, n, w, e, Z, n, info));
   }
-  {
+  const char* qmode = getenv("PMD_APPLY_Q");
+  if (qmode && !strcmp(qmode, "rocsolver")) {
     pmd_prof_scope prof__(ctx, "rocsolver_sormtr");
     PMD_BLAS(ctx, rocsolver_sormtr(ctx->blas, rocblas_side_left, rocblas_fill_lower, rocblas_operation_none, n, n, A,
                                    (rocblas_int)lda, tau, Z, n));
+  } else {
+    rc = pmd_apply_q_impl(ctx, n, A, lda, tau, Z, n, tws, tb);
+    if (rc != PMD_OK) return rc;
   }
   hipLaunchKernelGGL(copy_rows_kernel, dim3(8, n), dim3(256), 0, ctx->stream, Z, (long)n, A, lda, n);
   PMD_LAUNCH_CHECK(ctx, "copy_rows_kernel");

@@ -120,6 +120,18 @@ def _to_host(t):
     return out.numpy()
 
 
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    """One extra HIP stream per device for result downloads that overlap compute."""
+    torch = _torch()
+    key = str(device)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[key]
+
+
 def _sparse_u(ut_host, ranks, pix_f, block_weights, inv_cumw_rows, n_rows):
     """Sparse assembly of decomposition.py:812-853 (COO triplets, weights, row normalisation),
     vectorised.  ut_host: (n_tiles, 64, dpad) float32; pix_f: (n_tiles, d) row ids of the output
@@ -648,14 +660,44 @@ def localmd_decomposition(
         else:
             display("Tall matrix, using rightward SVD routine")
         Vp = torch.empty((rp, T), dtype=torch.float32, device=ctx.device) if return_diagnostics else None
+        extra_row = 1 if K_cols != max(K, 0) else 0  # the reference's placeholder background column (a zero row of R)
+        hosts = None
         if use_right and rp <= T:
             nk = rp
             R_out = torch.empty((Rc, nk), dtype=torch.float32, device=ctx.device)
             s_out = torch.empty((nk,), dtype=torch.float32, device=ctx.device)
             Vt_out = torch.empty((nk, T), dtype=torch.float32, device=ctx.device)
+            X1 = torch.empty((m_used, rp), dtype=torch.float32, device=ctx.device)
             ws = ctx.workspace(lib.pmd_projected_svd_factored_workspace_bytes(Rc, m_used, rp, T))
             ctx.call("pmd_projected_svd_factored", ptr(right), Rc, m_used, m_cols, ptr(Et_dev), rp, m_cols, ptr(Z), T, T,
-                     ptr(R_out), nk, ptr(s_out), ptr(Vt_out), T, ptr(Vp), T, ptr(ws), ws.numel())
+                     None, nk, ptr(s_out), ptr(Vt_out), T, ptr(Vp), T, ptr(X1), ptr(ws), ws.numel())
+            # R = right X1 in row blocks; s, Vt and every finished block go to the host on a side stream
+            # while the next block is computed (2.6 GB of results, ~45 ms of PCIe time otherwise serial)
+            main = torch.cuda.current_stream(ctx.device)
+            side = _side_stream(ctx.device)
+            r_host = torch.empty((Rc + extra_row, nk), dtype=torch.float32, pin_memory=True)
+            s_host = torch.empty((nk,), dtype=torch.float32, pin_memory=True)
+            vt_host = torch.empty((nk, T), dtype=torch.float32, pin_memory=True)
+            if extra_row:
+                r_host[Rc:].zero_()
+            ev = torch.cuda.Event()
+            ev.record(main)
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                s_host.copy_(s_out, non_blocking=True)
+                vt_host.copy_(Vt_out, non_blocking=True)
+            blk = max(1024, -(-Rc // 8 // 256) * 256)
+            for r0 in range(0, Rc, blk):
+                r1 = min(Rc, r0 + blk)
+                ctx.call("pmd_gemm", 0, 0, r1 - r0, nk, m_used, 1.0, ptr(right[r0:]), m_cols, ptr(X1), rp, 0.0,
+                         ptr(R_out[r0:]), nk)
+                ev = torch.cuda.Event()
+                ev.record(main)
+                side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    r_host[r0:r1].copy_(R_out[r0:r1], non_blocking=True)
+            side.synchronize()
+            hosts = (r_host.numpy(), s_host.numpy(), vt_host.numpy())
         else:
             if P_dev is None:  # factored P with R' > T (rank_prune corner): materialise P = right Et^T
                 P_dev = torch.empty((Rc, m_cols), dtype=torch.float32, device=ctx.device)
@@ -668,11 +710,14 @@ def localmd_decomposition(
         ctx.sync()
         lap("final_svd", t0)
         t0 = time.perf_counter()
-        r_mat = _to_host(R_out)
-        s = _to_host(s_out)
-        vt = _to_host(Vt_out)
-        if K_cols != max(K, 0):
-            r_mat = np.concatenate([r_mat, np.zeros((1, r_mat.shape[1]), dtype=r_mat.dtype)], axis=0)
+        if hosts is not None:
+            r_mat, s, vt = hosts
+        else:
+            r_mat = _to_host(R_out)
+            s = _to_host(s_out)
+            vt = _to_host(Vt_out)
+            if extra_row:
+                r_mat = np.concatenate([r_mat, np.zeros((1, r_mat.shape[1]), dtype=r_mat.dtype)], axis=0)
         good_components = s != 0
         if not np.all(good_components):
             r_mat = r_mat[:, good_components]
