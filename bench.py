@@ -150,6 +150,25 @@ def main():
         "algorithmic_gb_per_launch": bytes_per_launch / 1e9,
         "hbm_gbs_equiv": bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
     }
+    roofline_mfma = roofline
+    # Dominant kernel by time: sytrd_symv (triangle matrix-vector product of the tridiagonalisation behind the
+    # final SVD, one launch per column of the min(R', T)-sized Gram matrix).  Algorithmic bytes per launch =
+    # 4 B x the n'(n'+1)/2 entries of the trailing triangle (n' = n - j - 1); with profiling on, the library
+    # times every 64th launch (j = 32, 96, ...) on its stream: average bytes / average duration of that sample.
+    sv_ms, sv_n = prof.get("sytrd_symv_sample", (0.0, 0))
+    n_eig = min(int(diag["rank_after"]), cfg["T"])
+    if sv_n > 0:
+        js = np.arange(32, n_eig - 1, 64, dtype=np.float64)
+        npr = n_eig - js - 1
+        avg_bytes = float(np.mean(4.0 * npr * (npr + 1) / 2))
+        avg_sv_ms = sv_ms / sv_n
+        ach = avg_bytes / (avg_sv_ms * 1e-3) / 1e9
+        roofline = {
+            "kernel": "sytrd_symv (triangle symv of the Householder tridiagonalisation, fp32)", "bound": "hbm",
+            "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+            "avg_launch_ms": avg_sv_ms, "launches_timed": sv_n, "launches_per_step": n_eig - 1,
+            "algorithmic_mb_per_launch": avg_bytes / 1e6, "matrix_order": n_eig,
+        }
     out = {
         "metric": "frames/sec PMD decomposition", "value": value, "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
@@ -161,6 +180,7 @@ def main():
                    "parallelism": "1 process per GPU" + (f", tile grid sharded over {world} ranks, gather, replicated "
                                                           "global recombination" if world > 1 else "")},
         "roofline": roofline,
+        "roofline_mfma": roofline_mfma,
         "phases_ms": {k: 1e3 * v for k, v in diag["timings"].items()},
         "kernel_ms_per_step": {k: v[0] / args.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
     }

@@ -561,7 +561,11 @@ int pmd_sytrd_impl(pmd_ctx* ctx, int n, float* A, long lda, float* d, float* e, 
       for (int p = 0; p < npairs; ++p) nqx = std::max(nqx, nq(p) + ((nbk - 1 - p != p) ? nq(nbk - 1 - p) : 0));
       const int ndch = (i > 0) ? (n - cs + DCH - 1) / DCH : 0;
       const int drows = (ndch + nqx - 1) / nqx;
-      hipLaunchKernelGGL(sytrd_symv_kernel, dim3(nqx, npairs + drows), dim3(512), 0, st, A, lda, n, j, j0, B, ga, npairs, nbk, e, tau);
+      {
+        // with profiling on, every 64th column's product is timed on its own (bench.py: roofline of this kernel)
+        pmd_prof_scope sample__((ctx->profile && (j & 63) == 32) ? ctx : nullptr, "sytrd_symv_sample");
+        hipLaunchKernelGGL(sytrd_symv_kernel, dim3(nqx, npairs + drows), dim3(512), 0, st, A, lda, n, j, j0, B, ga, npairs, nbk, e, tau);
+      }
       nsp = nqx * npairs;
     }
     PMD_LAUNCH_CHECK(ctx, "sytrd panel");

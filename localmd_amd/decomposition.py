@@ -475,6 +475,12 @@ def localmd_decomposition(
                      ptr(v_dev[t_lo:]), ldv, 2)
         for tns in (ut_dev, stats_dev, good_dev, keep_dev, ranks_dev, lam_dev):
             dist.gather_runs(tns, runs)
+        # geometry-only host tables of the assembly and of U^T U, built while the tile kernels run
+        fov_ids = np.arange(D).reshape((d1, d2), order=order)
+        cumw = grid.cumulative_weights((d1, d2), block_sizes, origins, block_weights)
+        cover1, cover2 = grid.cover_tables((d1, d2), block_sizes, dim_1_iters, dim_2_iters)
+        pairs = grid.overlap_pairs(origins, block_sizes)
+        inv_cumw_host = np.ascontiguousarray(1.0 / cumw.reshape(-1))
         ctx.sync()
         lap("tiles", t0)
         _dbg("ut", ut_dev); _dbg("v_tiles", v_dev[:, :, :crop]); _dbg("tile_lambda", lam_dev)
@@ -487,12 +493,9 @@ def localmd_decomposition(
         K_cols = K if K > 0 else 1  # K <= 0: one empty placeholder column (pmd_loader.py:301-302)
         R = Rt + K_cols
         Rc = Rt + max(K, 0)         # columns with content
-        fov_ids = np.arange(D).reshape((d1, d2), order=order)
-        cumw = grid.cumulative_weights((d1, d2), block_sizes, origins, block_weights)
-        cover1, cover2 = grid.cover_tables((d1, d2), block_sizes, dim_1_iters, dim_2_iters)
         col_off_dev = _i32(ctx, offsets[:-1])
         w_dev = _f32(ctx, block_weights.reshape(-1, order="F"))
-        inv_cumw_dev = torch.from_numpy(np.ascontiguousarray(1.0 / cumw.reshape(-1))).to(ctx.device)
+        inv_cumw_dev = torch.from_numpy(inv_cumw_host).to(ctx.device)
         cov1_dev, cov2_dev = _i32(ctx, cover1), _i32(ctx, cover2)
         o1_dev, o2_dev = _i32(ctx, dim_1_iters), _i32(ctx, dim_2_iters)
         row_nnz = torch.empty(D, dtype=torch.int64, device=ctx.device)
@@ -510,9 +513,22 @@ def localmd_decomposition(
                  max(K, 0), Rt, ptr(indptr_dev), ptr(data_dev), ptr(idx_dev), ptr(zero_dev))
         ut_host = None
         basis_rows = None
+        u_pending = None
         if int(zero_dev.item()) == 0 and nnz < 2 ** 31:
-            u_r = scipy.sparse.csr_matrix(
-                (_to_host(data_dev[:nnz]), _to_host(idx_dev[:nnz]), indptr_dev.cpu().numpy().astype(np.int32)), shape=(D, R))
+            # the CSR arrays go to the host on the side stream while the global stage runs
+            side = _side_stream(ctx.device)
+            u_host = (torch.empty(nnz, dtype=torch.float64, pin_memory=True),
+                      torch.empty(nnz, dtype=torch.int32, pin_memory=True),
+                      torch.empty(D + 1, dtype=torch.int64, pin_memory=True))
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(ctx.device))
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                u_host[0].copy_(data_dev[:nnz], non_blocking=True)
+                u_host[1].copy_(idx_dev[:nnz], non_blocking=True)
+                u_host[2].copy_(indptr_dev, non_blocking=True)
+            u_pending = (u_host, data_dev, idx_dev, indptr_dev)  # keeps the device arrays alive until the copy is done
+            u_r = None
         else:
             # exact zeros present (the reference drops them, decomposition.py:853): host construction
             ut_host = ut_dev.cpu().numpy()
@@ -537,7 +553,6 @@ def localmd_decomposition(
         uw_dev = torch.empty_like(ut_dev)
         ctx.call("pmd_weight_tiles", ptr(ut_dev), dpad, ptr(pix_dev), d, ptr(w_dev), ptr(cumw_dev), ptr(ranks_dev),
                  ptr(uw_dev), n_tiles)
-        pairs = grid.overlap_pairs(origins, block_sizes)
         pairs_dev, origins_dev = _i32(ctx, pairs), _i32(ctx, origins)
 
         # v_cropped = [tile traces ; background temporal basis] (decomposition.py:844, :932)
@@ -710,6 +725,12 @@ def localmd_decomposition(
         ctx.sync()
         lap("final_svd", t0)
         t0 = time.perf_counter()
+        if u_pending is not None:
+            _side_stream(ctx.device).synchronize()
+            u_host = u_pending[0]
+            u_r = scipy.sparse.csr_matrix((u_host[0].numpy(), u_host[1].numpy(), u_host[2].numpy().astype(np.int32)),
+                                          shape=(D, R))
+            u_pending = None
         if hosts is not None:
             r_mat, s, vt = hosts
         else:

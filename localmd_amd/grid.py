@@ -134,22 +134,33 @@ def pooling_maps(block_sizes, n):
 
 def overlap_pairs(origins, block_sizes):
     """All (a <= b) tile pairs whose rectangles intersect, with the intersection rectangle
-    (i0, i1, j0, j1) in FOV coordinates.  int32 (n_pairs, 6)."""
+    (i0, i1, j0, j1) in FOV coordinates, ordered by (a, b).  int32 (n_pairs, 6).
+    `origins` is the row-major product grid of the tile-row and tile-column origins (tile_origins)."""
     b1, b2 = block_sizes
-    ks = np.unique(origins[:, 0])
-    js = np.unique(origins[:, 1])
-    index = {(int(k), int(j)): t for t, (k, j) in enumerate(origins)}
-    pairs = []
-    for t, (k, j) in enumerate(origins):
-        for k2 in ks[(ks > k - b1) & (ks < k + b1)]:
-            for j2 in js[(js > j - b2) & (js < j + b2)]:
-                t2 = index[(int(k2), int(j2))]
-                if t2 < t:
-                    continue
-                i0, i1 = max(k, k2), min(k, k2) + b1
-                j0, j1 = max(j, j2), min(j, j2) + b2
-                pairs.append((t, t2, i0, i1, j0, j1))
-    return np.asarray(pairs, dtype=np.int32).reshape(-1, 6)
+    origins = np.asarray(origins)
+    ks = np.unique(origins[:, 0]).astype(np.int64)
+    js = np.unique(origins[:, 1]).astype(np.int64)
+    n2 = len(js)
+    if len(ks) * n2 != len(origins):
+        raise ValueError("origins must be the full product grid of tile-row and tile-column origins")
+
+    def near(o, b):
+        # index pairs (p, q) of origins closer than one block: their tiles share pixels along this axis
+        p, q = np.nonzero(np.abs(o[:, None] - o[None, :]) < b)
+        return p, q
+
+    ra, rb = near(ks, b1)
+    ca, cb = near(js, b2)
+    ta = (ra[:, None] * n2 + ca[None, :]).reshape(-1)
+    tb = (rb[:, None] * n2 + cb[None, :]).reshape(-1)
+    i0 = np.broadcast_to(np.maximum(ks[ra], ks[rb])[:, None], (len(ra), len(ca))).reshape(-1)
+    i1 = np.broadcast_to(np.minimum(ks[ra], ks[rb])[:, None] + b1, (len(ra), len(ca))).reshape(-1)
+    j0 = np.broadcast_to(np.maximum(js[ca], js[cb])[None, :], (len(ra), len(ca))).reshape(-1)
+    j1 = np.broadcast_to(np.minimum(js[ca], js[cb])[None, :] + b2, (len(ra), len(ca))).reshape(-1)
+    keep = tb >= ta
+    out = np.stack([ta, tb, i0, i1, j0, j1], axis=1)[keep]
+    out = out[np.lexsort((out[:, 1], out[:, 0]))]
+    return np.ascontiguousarray(out, dtype=np.int32).reshape(-1, 6)
 
 
 def cumulative_weights(fov, block_sizes, origins, block_weights):

@@ -412,3 +412,32 @@ def test_syevd_own_path(gpu_ctx, n, force, monkeypatch):
     np.testing.assert_allclose(wv, np.linalg.eigvalsh(S64), atol=3e-6 * np.abs(S64).max() * np.sqrt(n))
     assert np.abs(E @ E.T - np.eye(n)).max() < 5e-5 * np.sqrt(n)
     assert np.abs(E @ S64 - wv[:, None] * E).max() < 1e-5 * np.abs(S64).max() * np.sqrt(n)
+
+
+@pytest.mark.parametrize("m", [90, 300, 515])
+def test_orthogonalize_chol_blocked(gpu_ctx, m):
+    """Et = U_c^{-T} with M^T (G M) = U_c^T U_c: lower triangular, Et C Et^T = I (several 128-blocks)."""
+    import ctypes as C
+
+    torch = _t()
+    ctx = gpu_ctx
+    lib = ctx.lib
+    rng = np.random.default_rng(m)
+    Rc = 2 * m + 37
+    M = rng.standard_normal((Rc, m)).astype(np.float32)
+    Md = dev(ctx, M)
+    Et = torch.full((m, m), float("nan"), dtype=torch.float32, device=ctx.device)
+    ok = C.c_int(0)
+    ws = ctx.workspace(lib.pmd_orthogonalize_chol_workspace_bytes(Rc, m))
+    ctx.call("pmd_orthogonalize_chol", P(Md), Rc, m, m, P(Md), m, P(Et), m, C.byref(ok), P(ws), ws.numel())
+    ctx.sync()
+    assert ok.value == 1
+    E = Et.cpu().numpy().astype(np.float64)
+    assert np.all(np.isfinite(E))
+    assert np.abs(np.triu(E, 1)).max() == 0.0
+    Cm = M.astype(np.float64).T @ M.astype(np.float64)
+    assert np.abs(E @ Cm @ E.T - np.eye(m)).max() < 2e-4
+    # not positive definite -> ok = 0, no exception
+    Z = torch.zeros((Rc, m), dtype=torch.float32, device=ctx.device)
+    ctx.call("pmd_orthogonalize_chol", P(Z), Rc, m, m, P(Z), m, P(Et), m, C.byref(ok), P(ws), ws.numel())
+    assert ok.value == 0
