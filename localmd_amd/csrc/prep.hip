@@ -8,6 +8,7 @@
 // trace is contiguous, so a tile is a gather of d rows and every row segment is a whole
 // 128-B line whatever the tile origin is.
 #include "pmd_internal.h"
+#include "fft_tables.h"
 
 // ---- tables: [0,256) Hann window (periodic); [256,320) cos, [320,384) sin of 2*pi*k/128;
 //              [384,513) cos, [513,642) sin of 2*pi*k/256 (k = 0..128)
@@ -37,18 +38,23 @@ int pmd_init_tables(pmd_ctx* ctx) {
 
 __device__ __forceinline__ int bitrev7(int x) { return (int)(__brev((unsigned)x) >> 25); }
 
-// One wave = 64 consecutive pixels x one 1024-frame chunk.  Every lane runs its own pixel's Welch
-// estimate; its 128-point complex FFT (real-input trick: z[n] = y[2n] + i y[2n+1]) lives in an LDS
-// column of float2 (index*64 + lane): lanes never share a bank, no barrier is needed, and every
-// butterfly is two ds_read_b64 + one broadcast twiddle read + two ds_write_b64.
+// One lane = one pixel x one 1024-frame chunk (frames-first movie: a wave reads 64 consecutive pixels of a
+// frame, 256 B).  Every lane runs its own Welch estimate (pmd_loader.py:203-291, preprocessing_utils.py:10-40):
+// 256-frame Hann windows at 50 % overlap, constant detrend, one-sided density averaged over the upper half band.
+// The 256 frames of a window are loaded into registers in one batch (256 independent loads in flight per lane),
+// and the real-input FFT (z[n] = y[2n] + i y[2n+1], 128 complex points) runs IN REGISTERS, fully unrolled with
+// compile-time twiddles (fft_tables.h): no LDS, so occupancy is set by the 256-VGPR window, not by a 64 KB
+// LDS column block.  Decimation in frequency: natural-order input, bit-reversed output positions (compile time).
+__device__ __forceinline__ constexpr int bitrev7c(int x) {
+  int r = 0;
+  for (int b = 0; b < 7; ++b) r |= ((x >> b) & 1) << (6 - b);
+  return r;
+}
+
 __global__ __launch_bounds__(64) void stats_chunk_kernel(const float* __restrict__ Y, int T, long D, int frame_const,
                                                          int do_noise, const float* __restrict__ tab,
                                                          double* __restrict__ chunk_sum, float* __restrict__ chunk_noise) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float2* z = reinterpret_cast<float2*>(lds);            // [128][64]
-  float2* tw = z + 128 * 64;                             // [64]  exp(-2 pi i k / 128)
-  float2* tw256 = tw + 64;                               // [129] exp(-2 pi i k / 256)
-  float* win = reinterpret_cast<float*>(tw256 + 130);    // [256]
+  (void)tab;
   const int lane = threadIdx.x;
   const long c = (long)blockIdx.x * 64 + lane;
   const bool valid = c < D;
@@ -57,95 +63,92 @@ __global__ __launch_bounds__(64) void stats_chunk_kernel(const float* __restrict
   const int t0 = chunk * frame_const;
   const int t1 = min(T, t0 + frame_const);
   const int n = t1 - t0;
+  const bool noise = do_noise && n >= 256;
+  const int nseg = noise ? (n - 128) / 128 : 0;
+  const int nhalf = noise ? nseg + 1 : 0;  // full 128-frame halves consumed by the windows
 
-  // batches of 32 independent loads per lane (the pass is latency bound otherwise: two waves per CU)
   double s = 0.0;
-  int t = t0;
-  for (; t + 32 <= t1; t += 32) {
-    float v[32];
-#pragma unroll
-    for (int u = 0; u < 32; ++u) v[u] = Y[(long)(t + u) * D + cc];
-    double part = 0.0;
-#pragma unroll
-    for (int u = 0; u < 32; ++u) part += (double)v[u];
-    s += part;
-  }
-  for (; t < t1; ++t) s += (double)Y[(long)t * D + cc];
-  if (valid) chunk_sum[(long)chunk * D + c] = s;
-  if (!do_noise || n < 256) {
-    if (valid && do_noise) chunk_noise[(long)chunk * D + c] = 0.f;
-    return;
-  }
-  tw[lane] = make_float2(tab[TAB_C128 + lane], -tab[TAB_S128 + lane]);
-  for (int k = lane; k <= 128; k += 64) tw256[k] = make_float2(tab[TAB_C256 + k], -tab[TAB_S256 + k]);
-  for (int i = lane; i < 256; i += 64) win[i] = tab[TAB_WIN + i];
-  __builtin_amdgcn_s_waitcnt(0);
-  __builtin_amdgcn_wave_barrier();
-
-  const int nseg = (n - 128) / 128;
   float acc = 0.f;
+  const float* ybase = Y + (long)t0 * D + cc;
   for (int seg = 0; seg < nseg; ++seg) {
-    const float* yp = Y + (long)(t0 + seg * 128) * D + cc;
-    double msum = 0.0;
-    for (int i = 0; i < 256; i += 32) {
-      float v[32];
+    const float* yp = ybase + (long)seg * 128 * D;
+    float re[128], im[128];
 #pragma unroll
-      for (int u = 0; u < 32; ++u) v[u] = yp[(long)(i + u) * D];
-      double part = 0.0;
-#pragma unroll
-      for (int u = 0; u < 32; ++u) part += (double)v[u];
-      msum += part;
+    for (int u = 0; u < 128; ++u) {
+      re[u] = yp[(long)(2 * u) * D];
+      im[u] = yp[(long)(2 * u + 1) * D];
     }
-    const float m = (float)(msum * (1.0 / 256.0));
-    for (int i = 0; i < 128; i += 16) {
-      float va[16], vb[16];
+    // sums of the two halves (frames 0..127 = points 0..63): 32-term float partials, then double
+    double h0 = 0.0, h1 = 0.0;
 #pragma unroll
-      for (int u = 0; u < 16; ++u) { va[u] = yp[(long)(2 * (i + u)) * D]; vb[u] = yp[(long)(2 * (i + u) + 1) * D]; }
+    for (int g = 0; g < 8; ++g) {
+      float p0 = 0.f, p1 = 0.f;
 #pragma unroll
-      for (int u = 0; u < 16; ++u)
-        z[bitrev7(i + u) * 64 + lane] = make_float2((va[u] - m) * win[2 * (i + u)], (vb[u] - m) * win[2 * (i + u) + 1]);
+      for (int u = 0; u < 16; ++u) {
+        p0 += re[g * 16 + u];
+        p1 += im[g * 16 + u];
+      }
+      if (g < 4) h0 += (double)p0 + (double)p1; else h1 += (double)p0 + (double)p1;
     }
-    // radix-2 decimation-in-time, in place
-#pragma unroll 1
-    for (int half = 1; half < 128; half <<= 1) {
-      const int tw_step = 64 / half;
-#pragma unroll 8
-      for (int j = 0; j < 64; ++j) {
-        const int k = j & (half - 1);
-        const int i0 = ((j - k) << 1) + k;
-        const int i1 = i0 + half;
-        const float2 w = tw[k * tw_step];
-        const float2 a = z[i0 * 64 + lane];
-        const float2 b = z[i1 * 64 + lane];
-        const float tr = b.x * w.x - b.y * w.y;
-        const float ti = b.x * w.y + b.y * w.x;
-        z[i0 * 64 + lane] = make_float2(a.x + tr, a.y + ti);
-        z[i1 * 64 + lane] = make_float2(a.x - tr, a.y - ti);
+    s += (seg == 0) ? (h0 + h1) : h1;  // every frame enters the chunk sum once
+    const float m = (float)((h0 + h1) * (1.0 / 256.0));
+#pragma unroll
+    for (int u = 0; u < 128; ++u) {
+      re[u] = (re[u] - m) * kWin256[2 * u];
+      im[u] = (im[u] - m) * kWin256[2 * u + 1];
+    }
+    // radix-2 decimation in frequency, in place: X[k] ends at position bitrev7(k)
+#pragma unroll
+    for (int len = 128; len >= 2; len >>= 1) {
+      const int half = len >> 1, step = 128 / len;
+#pragma unroll
+      for (int blk = 0; blk < 128; blk += len) {
+#pragma unroll
+        for (int k = 0; k < half; ++k) {
+          const int i0 = blk + k, i1 = i0 + half;
+          const float wr = kC128[k * step], wi = -kS128[k * step];
+          const float ar = re[i0], ai = im[i0], br = re[i1], bi = im[i1];
+          re[i0] = ar + br;
+          im[i0] = ai + bi;
+          const float dr = ar - br, di = ai - bi;
+          re[i1] = dr * wr - di * wi;
+          im[i1] = dr * wi + di * wr;
+        }
       }
     }
     // real-input unpack for bins 65..128: sum of one-sided power (x2 except Nyquist)
     float p = 0.f;
-#pragma unroll 4
+#pragma unroll
     for (int k = 65; k < 128; ++k) {
-      const float2 zk = z[k * 64 + lane];
-      const float2 zc = z[(128 - k) * 64 + lane];
-      const float cr = zc.x, ci = -zc.y;
-      const float er = 0.5f * (zk.x + cr), ei = 0.5f * (zk.y + ci);
+      const float zkr = re[bitrev7c(k)], zki = im[bitrev7c(k)];
+      const float cr = re[bitrev7c(128 - k)], ci = -im[bitrev7c(128 - k)];
+      const float er = 0.5f * (zkr + cr), ei = 0.5f * (zki + ci);
       // O = (Z - conj(Z'))/(2i) = (-i/2) * (dr + i di) = (di/2, -dr/2)
-      const float dr = zk.x - cr, di = zk.y - ci;
+      const float dr = zkr - cr, di = zki - ci;
       const float orr = 0.5f * di, oi = -0.5f * dr;
-      const float2 w = tw256[k];
-      const float xr = er + (orr * w.x - oi * w.y);
-      const float xi = ei + (orr * w.y + oi * w.x);
+      const float wr = kC256[k], wi = -kS256[k];
+      const float xr = er + (orr * wr - oi * wi);
+      const float xi = ei + (orr * wi + oi * wr);
       p += 2.0f * (xr * xr + xi * xi);
     }
-    const float2 z0 = z[lane];
-    const float xn = z0.x - z0.y;
+    const float xn = re[0] - im[0];
     p += xn * xn;
     acc += p;
   }
+  // frames not covered by a full half (chunk tail, or the whole chunk when it is too short for a window)
+  for (int t = t0 + nhalf * 128; t < t1; t += 32) {
+    float v[32];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) v[u] = Y[(long)min(t + u, t1 - 1) * D + cc];
+    double part = 0.0;
+#pragma unroll
+    for (int u = 0; u < 32; ++u) part += (t + u < t1) ? (double)v[u] : 0.0;
+    s += part;
+  }
+  if (valid) chunk_sum[(long)chunk * D + c] = s;
+  if (!do_noise) return;
   // density scaling 1/(fs*sum w^2) = 1/96; mean over segments; 0.5 * Pxx averaged over 64 bins
-  const float val = sqrtf(acc * (1.0f / 96.0f) / (float)nseg * 0.5f / 64.0f);
+  const float val = noise ? sqrtf(acc * (1.0f / 96.0f) / (float)nseg * 0.5f / 64.0f) : 0.f;
   if (valid) chunk_noise[(long)chunk * D + c] = val;
 }
 
@@ -186,9 +189,7 @@ int pmd_launch_stats(pmd_ctx* ctx, const float* movie, int T, long D, int frame_
     const int n = (k + 1 == nchunks) ? T - k * frame_const : frame_const;
     if (n >= 256) ncounted++;
   }
-  const size_t lds = 2 * 128 * 64 * sizeof(float) + (64 + 130) * sizeof(float2) + 256 * sizeof(float) + 64;
-  PMD_HIP(ctx, hipFuncSetAttribute((const void*)stats_chunk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(stats_chunk_kernel, dim3((unsigned)((D + 63) / 64), nchunks), dim3(64), lds, ctx->stream, movie, T,
+  hipLaunchKernelGGL(stats_chunk_kernel, dim3((unsigned)((D + 63) / 64), nchunks), dim3(64), 0, ctx->stream, movie, T,
                      D, frame_const, do_noise, ctx->tables, csum, cnoise);
   PMD_LAUNCH_CHECK(ctx, "stats_chunk_kernel");
   hipLaunchKernelGGL(stats_finalize_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, ctx->stream, csum, cnoise,
