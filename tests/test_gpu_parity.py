@@ -394,3 +394,26 @@ def test_full_pipeline_multi_window_residual(gpu_ctx):
     # the later windows must have contributed components in at least one tile
     first = np.array([d[0]["kept"].sum() for d in ref.diag["tile_diag"]])
     assert np.any(ref.diag["tile_ranks"] > first)
+
+
+def test_full_pipeline_rank_prune(gpu_ctx):
+    """rank_prune=True (decomposition.py:861-877): the right matrix is v_cropped times a Gaussian matrix
+    (device stream PRUNE, handed to the oracle as is)."""
+    mov = _movie(500, 40, 44, seed=5)
+    pmd, diag, ref = _compare_full(gpu_ctx, mov, (20, 20), 500, max_components=6, background_rank=2, sim_iters=10,
+                                   rank_prune=True, rank_prune_factor=0.5)
+    assert pmd.s.shape == ref.s.shape
+    _check_full(pmd, diag, ref, mov, vt_tol=5e-3, orth_tol=1e-2, s_tol=3e-3, vt_tol_signal=2e-3)
+
+
+def test_full_pipeline_pixel_weighting_and_c_order(gpu_ctx):
+    """pixel_weighting (decomposition.py:740-741) and order='C' (pmd_loader.py reshape order)."""
+    mov = _movie(400, 36, 40, seed=6)
+    rng = np.random.default_rng(3)
+    pw = (0.5 + rng.random((36, 40))).astype(np.float32)
+    pmd, diag, ref = _compare_full(gpu_ctx, mov, (18, 20), 400, max_components=5, background_rank=1, sim_iters=10,
+                                   pixel_weighting=pw, order="C")
+    # the weakest "signal" component of this case (sigma = 5.4 % of sigma_1, 2.7 % gap) sits at the fp32
+    # Gram-eigh limit eps (sigma_1/sigma_c)^2 / gap ~ 8e-4 of BOTH implementations; all others are < 4e-5
+    _check_full(pmd, diag, ref, mov, vt_tol_signal=6e-4)
+    assert pmd.order == "C"
