@@ -565,14 +565,27 @@ __global__ __launch_bounds__(256) void gram_apply_kernel(const float* __restrict
     for (int i = threadIdx.x; i < 64 * NOUT; i += 256) {
       const int cp = i / NOUT, c = i - cp * NOUT;
       // stored block is [row-tile comp][col-tile comp]; transposed flag: this tile is the column tile
-      g[cp][c] = (flags & 1) ? src[cp * 64 + c] : src[c * 64 + cp];
+      g[cp][c] = src[(flags & 1) ? cp * 64 + c : c * 64 + cp];
     }
     __syncthreads();
-    if (x < ncols) {
-      for (int cp = 0; cp < rb; ++cp) {
-        const float v = M[(long)(row0 + cp) * ldm + x];
+    // eight rows of M in flight per thread (unconditional loads on clamped indices), FMAs only for the
+    // 8-column groups below this tile's rank
+    const long xc = (x < ncols) ? x : ncols - 1;
+    for (int cp0 = 0; cp0 < rb; cp0 += 8) {
+      float v[8];
 #pragma unroll
-        for (int c = 0; c < NOUT; ++c) acc[c] = fmaf(g[cp][c], v, acc[c]);
+      for (int u = 0; u < 8; ++u) v[u] = M[(long)(row0 + ((cp0 + u < rb) ? cp0 + u : rb - 1)) * ldm + xc];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (cp0 + u < rb) {
+#pragma unroll
+          for (int c0 = 0; c0 < NOUT; c0 += 8) {
+            if (c0 < ra) {
+#pragma unroll
+              for (int c = c0; c < c0 + 8; ++c) acc[c] = fmaf(g[cp0 + u][c], v[u], acc[c]);
+            }
+          }
+        }
       }
     }
   }

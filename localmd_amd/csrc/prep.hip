@@ -250,18 +250,29 @@ __global__ __launch_bounds__(256) void filter_kernel(const float* __restrict__ i
                                                      const float* __restrict__ pj, long ldp) {
   const long f = (long)blockIdx.x * 256 + threadIdx.x;
   const long c0 = (long)blockIdx.y * 64;
-  if (f >= nf) return;
+  const bool live = f < nf;
+  const long fc = live ? f : nf - 1;
+  // loads are unconditional (clamped index, masked value): a guarded load compiles to a branch with a full wait
   float p[KMAX];
 #pragma unroll
-  for (int k = 0; k < KMAX; ++k) p[k] = (k < K) ? pj[(long)k * ldp + f] : 0.f;
+  for (int k = 0; k < KMAX; ++k) {
+    p[k] = pj[(long)((k < K) ? k : 0) * ldp + fc];
+    if (k >= K) p[k] = 0.f;
+  }
   const long c1 = (c0 + 64 < D) ? c0 + 64 : D;
-  for (long c = c0; c < c1; ++c) {
-    const float* b = basis + c * K;
-    float acc = 0.f;
+  for (long c = c0; c < c1; c += 8) {
+    float v[8];
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k)
-      if (k < K) acc = fmaf(b[k], p[k], acc);
-    out[c * ld + f] = in[c * ld + f] - acc;
+    for (int u = 0; u < 8; ++u) v[u] = in[((c + u < c1) ? c + u : c1 - 1) * ld + fc];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long cu = (c + u < c1) ? c + u : c1 - 1;
+      const float* b = basis + cu * K;
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) acc = fmaf(b[(k < K) ? k : 0], p[k], acc);
+      if (live && c + u < c1) out[cu * ld + f] = v[u] - acc;
+    }
   }
 }
 

@@ -471,10 +471,19 @@ __global__ __launch_bounds__(256) void tile_rowmix_kernel(const float* __restric
     double acc[NOUT];
 #pragma unroll
     for (int c = 0; c < NOUT; ++c) acc[c] = 0.0;
-    for (int cp = 0; cp < n_in; ++cp) {
-      const double v = (double)in[(long)cp * ld_in + x];
+    // eight input rows in flight per thread (clamped index: no branch between the loads)
+    for (int cp0 = 0; cp0 < n_in; cp0 += 8) {
+      float v[8];
 #pragma unroll
-      for (int c = 0; c < NOUT; ++c) acc[c] = fma(nm[cp * NOUT + c], v, acc[c]);
+      for (int u = 0; u < 8; ++u) v[u] = in[(long)((cp0 + u < n_in) ? cp0 + u : n_in - 1) * ld_in + x];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (cp0 + u < n_in) {
+          const double vd = (double)v[u];
+#pragma unroll
+          for (int c = 0; c < NOUT; ++c) acc[c] = fma(nm[(cp0 + u) * NOUT + c], vd, acc[c]);
+        }
+      }
     }
 #pragma unroll
     for (int c = 0; c < NOUT; ++c) out[(long)c * ld_out + x] = (c < n_out) ? (float)acc[c] : 0.f;
