@@ -843,7 +843,9 @@ __global__ __launch_bounds__(256) void potf2_block_kernel(float* __restrict__ A,
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int r = tr + 16 * i, c = tc + 16 * j;
-      a[i][j] = (r < nb && c <= r) ? A[(long)r * ld + c] : 0.f;
+      const bool in = r < nb && c <= r;
+      const float v = A[(long)(in ? r : 0) * ld + (in ? c : 0)];  // unconditional load, masked value
+      a[i][j] = in ? v : 0.f;
     }
   int bad = 0;
   for (int k = 0; k < nb; ++k) {
@@ -872,8 +874,9 @@ __global__ __launch_bounds__(256) void potf2_block_kernel(float* __restrict__ A,
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int r = tr + 16 * i, c = tc + 16 * i;
-      lr[i] = (r > k && r < nb) ? col[r] * inv : 0.f;
-      lc[i] = (c > k && c < nb) ? col[c] * inv : 0.f;
+      const float vr = col[r], vc = col[c];  // unconditional LDS reads (stale entries above the pivot are masked)
+      lr[i] = (r > k && r < nb) ? vr * inv : 0.f;
+      lc[i] = (c > k && c < nb) ? vc * inv : 0.f;
     }
     // only register columns j >= k / 16 and rows i >= j can still change (uniform tests: whole slabs are skipped)
 #pragma unroll
@@ -905,9 +908,11 @@ __global__ __launch_bounds__(256) void potf2_block_kernel(float* __restrict__ A,
 // Blocked right-looking Cholesky of the row-major lower triangle (= column-major upper, A = U^T U):
 // diagonal block in LDS, panel by rocBLAS strsm, trailing update by ssyrk.  rocSOLVER's spotrf spends half
 // of its 35 ms at n = 10^4 in its unblocked diagonal-block kernel.
-static int chol_lower_rm(pmd_ctx* ctx, int n, float* A, long ld, int* info) {
+// tmp: n x CHOL_NB floats (the panel before it is copied back), linv: CHOL_NB x CHOL_NB floats
+static int chol_lower_rm(pmd_ctx* ctx, int n, float* A, long ld, int* info, float* tmp, float* linv) {
   pmd_prof_scope prof__(ctx, "cholesky");
   PMD_HIP(ctx, hipMemsetAsync(info, 0, sizeof(int), ctx->stream));
+  PMD_HIP(ctx, hipMemsetAsync(linv, 0, sizeof(float) * CHOL_NB * CHOL_NB, ctx->stream));
   const float one = 1.f, minus1 = -1.f;
   for (int k0 = 0; k0 < n; k0 += CHOL_NB) {
     const int nb = std::min(CHOL_NB, n - k0);
@@ -918,11 +923,14 @@ static int chol_lower_rm(pmd_ctx* ctx, int n, float* A, long ld, int* info) {
     if (rest <= 0) break;
     float* P = A + (long)(k0 + nb) * ld + k0;        // row-major rest x nb  ==  column-major nb x rest
     float* T22 = A + (long)(k0 + nb) * ld + (k0 + nb);
-    // X L_kk^T = A21  <=>  (column-major) Lc^T Xc = A21c with Lc = L_kk^T upper
-    PMD_BLAS(ctx, rocblas_strsm(ctx->blas, rocblas_side_left, rocblas_fill_upper, rocblas_operation_transpose,
-                                rocblas_diagonal_non_unit, nb, rest, &one, D, (rocblas_int)ld, P, (rocblas_int)ld));
-    PMD_BLAS(ctx, rocblas_ssyrk(ctx->blas, rocblas_fill_upper, rocblas_operation_transpose, rest, nb, &minus1, P,
-                                (rocblas_int)ld, &one, T22, (rocblas_int)ld));
+    // L21 = A21 L_kk^{-T}: invert the 128 x 128 block (column-major upper view of the row-major lower block)
+    // and multiply - rocBLAS' strsm spends ~20 small launches per panel on the same thing
+    PMD_BLAS(ctx, rocblas_strtri(ctx->blas, rocblas_fill_upper, rocblas_diagonal_non_unit, nb, D, (rocblas_int)ld, linv, CHOL_NB));
+    RUN(pmd_gemm_rm(ctx, 0, 1, rest, nb, nb, 1.f, P, ld, linv, CHOL_NB, 0.f, tmp, CHOL_NB));
+    PMD_HIP(ctx, hipMemcpy2DAsync(P, (size_t)ld * sizeof(float), tmp, (size_t)CHOL_NB * sizeof(float), (size_t)nb * sizeof(float),
+                                  rest, hipMemcpyDeviceToDevice, ctx->stream));
+    PMD_BLAS(ctx, rocblas_ssyrk(ctx->blas, rocblas_fill_upper, rocblas_operation_transpose, rest, nb, &minus1, tmp,
+                                CHOL_NB, &one, T22, (rocblas_int)ld));
   }
   return PMD_OK;
 }
@@ -933,13 +941,17 @@ __global__ void tril_mask_kernel(float* __restrict__ A, long ld, int n) {
     if (j > i) A[(long)i * ld + j] = 0.f;
 }
 
-size_t pmd_orthogonalize_chol_workspace_bytes_impl(int Rc, int m) { return (size_t)m * Rc * sizeof(float) + 8192; }
+size_t pmd_orthogonalize_chol_workspace_bytes_impl(int Rc, int m) {
+  return (size_t)m * Rc * sizeof(float) + ((size_t)m + CHOL_NB) * CHOL_NB * sizeof(float) + 8192;
+}
 
 int pmd_orthogonalize_chol_impl(pmd_ctx* ctx, const float* M, int Rc, int m, long ldm, const float* GM, long ldgm,
                                 float* Et_out, long lde, int* ok_host, void* ws, size_t ws_bytes) {
   pmd_arena ar(ws, ws_bytes);
   int* info = ar.take_n<int>(4);
   float* Mt = ar.take_n<float>((size_t)m * Rc);
+  float* chol_tmp = ar.take_n<float>((size_t)m * CHOL_NB);
+  float* chol_linv = ar.take_n<float>((size_t)CHOL_NB * CHOL_NB);
   if (ar.overflow) return pmd_fail(ctx, PMD_ERR_WORKSPACE, "pmd_orthogonalize_chol", "workspace too small");
   *ok_host = 0;
   // C = M^T (G M): only the row-major lower triangle (= the column-major upper one potrf reads) is
@@ -957,7 +969,7 @@ int pmd_orthogonalize_chol_impl(pmd_ctx* ctx, const float* M, int Rc, int m, lon
       pmd_prof_scope prof__(ctx, "rocsolver_spotrf");
       PMD_BLAS(ctx, rocsolver_spotrf(ctx->blas, rocblas_fill_upper, m, Et_out, (rocblas_int)lde, info));
     } else {
-      RUN(chol_lower_rm(ctx, m, Et_out, lde, info));
+      RUN(chol_lower_rm(ctx, m, Et_out, lde, info, chol_tmp, chol_linv));
     }
   }
   PMD_HIP(ctx, hipMemcpyAsync(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
