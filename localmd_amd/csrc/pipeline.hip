@@ -227,7 +227,7 @@ int pmd_tiles_residual_impl(pmd_ctx* ctx, const float* Xw, long ldx, long n_rows
 // ------------------------------------------------------------------------------------------
 // threshold simulation (decomposition.py:76-131, :147-181): rank-1 rSVD of N(0,1) tiles
 // ------------------------------------------------------------------------------------------
-static const int SIM_BATCH = 50;
+static const int SIM_BATCH = 256;  // one batch for the reference's 250 iterations (~22 MB of workspace each)
 
 struct sim_plan {
   int dpad, nbatch;
