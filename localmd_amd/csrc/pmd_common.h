@@ -79,6 +79,30 @@ static inline int pmd_fail(pmd_ctx* ctx, int code, const char* what, const char*
 
 static inline long pmd_round_up(long x, long m) { return (x + m - 1) / m * m; }
 
+// XCD-aware tile order.  Workgroups go to the 8 XCDs round-robin by linear workgroup id, and each XCD has its
+// own L2.  Tiles overlap their neighbours by 50 %, so instead of dealing tiles 0,1,2,... across the XCDs, every
+// XCD gets a contiguous run of the tile list and walks it in order: neighbouring tiles then run on the same XCD
+// at about the same time and the second reader of a shared pixel row hits that XCD's L2.
+// For a grid whose x dimension counts tiles: returns the tile of this workgroup (a bijection on [0, gridDim.x)).
+#ifdef __HIPCC__
+__device__ __forceinline__ int pmd_xcd_tile() {
+  const int n = (int)gridDim.x, x = (int)blockIdx.x;
+  if (n < 64) return x;
+  const int row = (int)(blockIdx.y + gridDim.y * blockIdx.z);
+  const int s = (int)(((long)n * row) & 7);      // XCD of the first workgroup of this grid row
+  const int c = (x + s) & 7;                     // XCD of this workgroup
+  const int x0 = (c - s) & 7;                    // first x of the row that lands on XCD c
+  const int m = (x - x0) >> 3;                   // how many earlier workgroups of the row that XCD got
+  // tiles before XCD c's run: XCD c' owns the x values x0' = (c' - s) & 7, x0' + 8, ... below n
+  int off = 0;
+  for (int cp = 0; cp < c; ++cp) {
+    const int x0p = (cp - s) & 7;
+    off += (n - x0p + 7) >> 3;
+  }
+  return off + m;
+}
+#endif
+
 // carve a caller-provided workspace
 struct pmd_arena {
   char* base;

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256 * KS * NS) void tile_atx_kernel(const float* __
   float* red = lds + NBUF * DPAD * LSTR;
   constexpr int TRASH = NBUF * DPAD * LSTR + (KS - 1) * 2048;  // 16-byte slot nobody reads
 
-  const int tile = blockIdx.x;
+  const int tile = pmd_xcd_tile();
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int mt = wid & 3, ks = (NS == 1) ? (wid >> 2) : 0, nh = (NS == 1) ? 0 : (wid >> 2);
   const int n16 = lane & 15, kk = lane >> 4;
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void tile_xbt_kernel(const float* __restrict__
                                                        int d, const float* __restrict__ B, long b_tile_stride, long ldb,
                                                        float* __restrict__ S, long s_tile_stride, long s_slice_stride,
                                                        int s_ld, int n_groups_total, int groups_per_slice) {
-  const int tile = blockIdx.x;
+  const int tile = pmd_xcd_tile();
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int n16 = lane & 15, kk = lane >> 4;
   const int m0 = (blockIdx.z * 4 + wid) * MPW;  // first M tile of this wave

@@ -7,7 +7,7 @@ import sys
 acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
 with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
-        name = r["Kernel_Name"].split("(")[0][-60:]
+        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].split("<")[0][-60:]
         a = acc[name][r["Counter_Name"]]
         a[0] += 1
         a[1] += float(r["Counter_Value"])

@@ -16,7 +16,8 @@ X = torch.randn((n, n + 2000), device="cuda", generator=g)
 S = (X @ X.T).contiguous()
 del X
 d = torch.zeros(n, device="cuda"); e = torch.zeros(n, device="cuda"); tau = torch.zeros(n, device="cuda")
-for rep in range(2):
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+for rep in range(reps):
     A = S.clone()
     ctx.call("pmdk_sytrd", n, P(A), n, P(d), P(e), P(tau), impl)
     ctx.sync()
