@@ -177,8 +177,10 @@ def main():
                    "frames_to_init": cfg["frames"], "max_components": cfg["max_components"], "tiles": n_tiles,
                    "rank_before": diag["rank_before"], "rank_after": diag["rank_after"],
                    "mean_tile_rank": float(np.mean(diag["tile_ranks"])),
-                   "parallelism": "1 process per GPU" + (f", tile grid sharded over {world} ranks, gather, replicated "
-                                                          "global recombination" if world > 1 else "")},
+                   "parallelism": "1 process per GPU" + (
+                       f", tile grid and the rows of the global stage sharded over {world} ranks (tile results gathered, "
+                       "the two frames x frames Gram matrices all-reduced, R collected on rank 0; statistics and the "
+                       "m x m Cholesky / eigen stage replicated)" if world > 1 else "")},
         "roofline": roofline,
         "roofline_mfma": roofline_mfma,
         "phases_ms": {k: 1e3 * v for k, v in diag["timings"].items()},

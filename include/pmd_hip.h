@@ -164,9 +164,20 @@ size_t pmd_orthogonalize_chol_workspace_bytes(int Rc, int m);
 size_t pmd_projected_svd_factored_workspace_bytes(int Rc, int m, int rp, int T);
 int pmd_projected_svd_factored(pmd_ctx* ctx, const float* M, int Rc, int m, long ldm, const float* Et, int rp, long lde,
                                const float* Z, int T, long ldz, float* R_out, long ldr, float* s_out, float* Vt_out,
-                               long ldvt, float* Vp_out, long ldvp, float* X1_out, void* ws, size_t ws_bytes);
+                               long ldvt, float* Vp_out, long ldvp, float* X1_out, const float* W1_in, void* ws,
+                               size_t ws_bytes);
 /* (X1_out: optional m x rp, ld rp, receives Et^T W.  With R_out == NULL the last product R = M X1 is left to the
- * caller, who can then form R in row blocks with pmd_gemm and overlap their download with the next block.) */
+ * caller, who can then form R in row blocks with pmd_gemm and overlap their download with the next block.
+ * W1_in: optional m x T, ld T: M^T Z formed by the caller, e.g. the all-reduced sum of per-rank row-range partials.) */
+/* The two halves of pmd_orthogonalize_chol, for callers that shard the rows of M over ranks: the partial
+ * C = M[rows]^T GM[rows] (row-major lower block triangle; all-reduce it), then C -> Et in place. */
+size_t pmd_gram_mtgm_workspace_bytes(int rows, int m);
+int pmd_gram_mtgm(pmd_ctx* ctx, const float* M, int rows, int m, long ldm, const float* GM, long ldgm, float* C, long ldc,
+                  void* ws, size_t ws_bytes);
+size_t pmd_chol_inverse_workspace_bytes(int m);
+int pmd_chol_inverse(pmd_ctx* ctx, float* C, int m, long ldc, int* ok_host, void* ws, size_t ws_bytes);
+/* dst (cols x rows, ld_dst) = src (rows x cols, ld_src)^T, row-major */
+int pmd_transpose(pmd_ctx* ctx, const float* src, long ld_src, int rows, int cols, float* dst, long ld_dst);
 /* A13/A14: CSR arrays of the sparse spatial matrix built on the device (decomposition.py:812-853, :929-930);
  * cover1[d1][4] / cover2[d2][4]: indices of the tile-row / tile-column origins covering each FOV row / column. */
 int pmd_csr_count(pmd_ctx* ctx, int d1, int d2, int order_f, const int* cover1, const int* cover2, int n2,

@@ -277,15 +277,31 @@ int pmd_orthogonalize_chol(pmd_ctx* ctx, const float* M, int Rc, int m, long ldm
   return pmd_orthogonalize_chol_impl(ctx, M, Rc, m, ldm, GM, ldgm, Et_out, lde, ok_host, ws, ws_bytes);
 }
 size_t pmd_orthogonalize_chol_workspace_bytes(int Rc, int m) { return pmd_orthogonalize_chol_workspace_bytes_impl(Rc, m); }
+size_t pmd_gram_mtgm_workspace_bytes(int rows, int m) { return pmd_gram_mtgm_workspace_bytes_impl(rows, m); }
+int pmd_gram_mtgm(pmd_ctx* ctx, const float* M, int rows, int m, long ldm, const float* GM, long ldgm, float* C, long ldc,
+                  void* ws, size_t ws_bytes) {
+  CTX_CHECK(ctx);
+  return pmd_gram_mtgm_impl(ctx, M, rows, m, ldm, GM, ldgm, C, ldc, ws, ws_bytes);
+}
+size_t pmd_chol_inverse_workspace_bytes(int m) { return pmd_chol_inverse_workspace_bytes_impl(m); }
+int pmd_chol_inverse(pmd_ctx* ctx, float* C, int m, long ldc, int* ok_host, void* ws, size_t ws_bytes) {
+  CTX_CHECK(ctx);
+  return pmd_chol_inverse_impl(ctx, C, m, ldc, ok_host, ws, ws_bytes);
+}
+int pmd_transpose(pmd_ctx* ctx, const float* src, long ld_src, int rows, int cols, float* dst, long ld_dst) {
+  CTX_CHECK(ctx);
+  return pmd_transpose_impl(ctx, src, ld_src, rows, cols, dst, ld_dst);
+}
 size_t pmd_projected_svd_factored_workspace_bytes(int Rc, int m, int rp, int T) {
   return pmd_projected_svd_factored_workspace_bytes_impl(Rc, m, rp, T);
 }
 int pmd_projected_svd_factored(pmd_ctx* ctx, const float* M, int Rc, int m, long ldm, const float* Et, int rp, long lde,
                                const float* Z, int T, long ldz, float* R_out, long ldr, float* s_out, float* Vt_out,
-                               long ldvt, float* Vp_out, long ldvp, float* X1_out, void* ws, size_t ws_bytes) {
+                               long ldvt, float* Vp_out, long ldvp, float* X1_out, const float* W1_in, void* ws,
+                               size_t ws_bytes) {
   CTX_CHECK(ctx);
   return pmd_projected_svd_factored_impl(ctx, M, Rc, m, ldm, Et, rp, lde, Z, T, ldz, R_out, ldr, s_out, Vt_out, ldvt,
-                                         Vp_out, ldvp, X1_out, ws, ws_bytes);
+                                         Vp_out, ldvp, X1_out, W1_in, ws, ws_bytes);
 }
 
 // ---- kernel-level entry points ---------------------------------------------------------------

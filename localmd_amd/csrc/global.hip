@@ -794,8 +794,8 @@ size_t pmd_projected_svd_factored_workspace_bytes_impl(int Rc, int m, int rp, in
 // Vp_out (rp x T, optional, may be NULL) receives V = P^T Z.
 int pmd_projected_svd_factored_impl(pmd_ctx* ctx, const float* M, int Rc, int m, long ldm, const float* Et, int rp,
                                     long lde, const float* Z, int T, long ldz, float* R_out, long ldr, float* s_out,
-                                    float* Vt_out, long ldvt, float* Vp_out, long ldvp, float* X1_out, void* ws,
-                                    size_t ws_bytes) {
+                                    float* Vt_out, long ldvt, float* Vp_out, long ldvp, float* X1_out,
+                                    const float* W1_in, void* ws, size_t ws_bytes) {
   if (rp > T) return pmd_fail(ctx, PMD_ERR_UNSUPPORTED, "pmd_projected_svd_factored", "needs R' <= T");
   pmd_arena ar(ws, ws_bytes);
   float* W1 = ar.take_n<float>((size_t)m * T);
@@ -809,9 +809,12 @@ int pmd_projected_svd_factored_impl(pmd_ctx* ctx, const float* M, int Rc, int m,
   // M^T Z as a plain (non-transposed) product of an explicit copy of M^T: rocBLAS' transposed-A kernels
   // reach half the rate of the plain ones at K = Rc ~ 5e4 (72 vs 147 TFLOP/s, scripts/gemm_probe.hip),
   // and the copy is one 2 x 4 Rc m byte pass
-  RUN(launch_transpose(ctx, M, ldm, Rc, m, Mt, Rc));
-  RUN(pmd_gemm_rm(ctx, 0, 0, m, T, Rc, 1.f, Mt, Rc, Z, ldz, 0.f, W1, T));      // M^T Z
-  RUN(pmd_gemm_rm(ctx, 0, 0, rp, T, m, 1.f, Et, lde, W1, T, 0.f, Vp, ldv));     // V = Et (M^T Z)
+  if (!W1_in) {
+    RUN(launch_transpose(ctx, M, ldm, Rc, m, Mt, Rc));
+    RUN(pmd_gemm_rm(ctx, 0, 0, m, T, Rc, 1.f, Mt, Rc, Z, ldz, 0.f, W1, T));      // M^T Z
+  }
+  // (W1_in: the caller has formed M^T Z already, e.g. as an all-reduced sum of per-rank row-range partials)
+  RUN(pmd_gemm_rm(ctx, 0, 0, rp, T, m, 1.f, Et, lde, W1_in ? W1_in : W1, T, 0.f, Vp, ldv));     // V = Et (M^T Z)
   // SVD of V with the identity as projection: the "R" it returns is W (rp x rp), reuse W1's memory
   float* Wmat = W1;  // rp x rp  (rp <= m, T)
   RUN(pmd_projected_svd_impl(ctx, nullptr, 0, 0, Vp, rp, T, ldv, Wmat, rp, s_out, Vt_out, ldvt, sub, sub_bytes));
@@ -942,34 +945,47 @@ __global__ void tril_mask_kernel(float* __restrict__ A, long ld, int n) {
 }
 
 size_t pmd_orthogonalize_chol_workspace_bytes_impl(int Rc, int m) {
-  return (size_t)m * Rc * sizeof(float) + ((size_t)m + CHOL_NB) * CHOL_NB * sizeof(float) + 8192;
+  return (size_t)m * Rc * sizeof(float) + ((size_t)m + CHOL_NB) * CHOL_NB * sizeof(float) + 16384;
 }
 
-int pmd_orthogonalize_chol_impl(pmd_ctx* ctx, const float* M, int Rc, int m, long ldm, const float* GM, long ldgm,
-                                float* Et_out, long lde, int* ok_host, void* ws, size_t ws_bytes) {
+// C (row-major lower block triangle, the part the Cholesky step reads) = M^T GM over `rows` rows of both.
+// With the tile rows sharded over ranks every rank passes its own row range and the partial C are all-reduced.
+size_t pmd_gram_mtgm_workspace_bytes_impl(int rows, int m) { return (size_t)m * rows * sizeof(float) + 4096; }
+
+int pmd_gram_mtgm_impl(pmd_ctx* ctx, const float* M, int rows, int m, long ldm, const float* GM, long ldgm, float* C,
+                       long ldc, void* ws, size_t ws_bytes) {
+  if (rows <= 0) return PMD_OK;
   pmd_arena ar(ws, ws_bytes);
-  int* info = ar.take_n<int>(4);
-  float* Mt = ar.take_n<float>((size_t)m * Rc);
-  float* chol_tmp = ar.take_n<float>((size_t)m * CHOL_NB);
-  float* chol_linv = ar.take_n<float>((size_t)CHOL_NB * CHOL_NB);
-  if (ar.overflow) return pmd_fail(ctx, PMD_ERR_WORKSPACE, "pmd_orthogonalize_chol", "workspace too small");
-  *ok_host = 0;
-  // C = M^T (G M): only the row-major lower triangle (= the column-major upper one potrf reads) is
-  // formed, in row blocks C[i0:i0+bs, 0:i0+bs] = Mt[i0:i0+bs, :] GM[:, 0:i0+bs]  (9/16 of the flops at 8 blocks)
-  RUN(launch_transpose(ctx, M, ldm, Rc, m, Mt, Rc));
+  float* Mt = ar.take_n<float>((size_t)m * rows);
+  if (ar.overflow) return pmd_fail(ctx, PMD_ERR_WORKSPACE, "pmd_gram_mtgm", "workspace too small");
+  // row blocks C[i0:i0+bs, 0:i0+bs] = Mt[i0:i0+bs, :] GM[:, 0:i0+bs]  (9/16 of the flops at 8 blocks)
+  RUN(launch_transpose(ctx, M, ldm, rows, m, Mt, rows));
   const int bs = std::max(256, ((m + 7) / 8 + 255) / 256 * 256);
   for (int i0 = 0; i0 < m; i0 += bs) {
-    const int rows = std::min(bs, m - i0);
-    RUN(pmd_gemm_rm(ctx, 0, 0, rows, i0 + rows, Rc, 1.f, Mt + (long)i0 * Rc, Rc, GM, ldgm, 0.f, Et_out + (long)i0 * lde, lde));
+    const int nr = std::min(bs, m - i0);
+    RUN(pmd_gemm_rm(ctx, 0, 0, nr, i0 + nr, rows, 1.f, Mt + (long)i0 * rows, rows, GM, ldgm, 0.f, C + (long)i0 * ldc, ldc));
   }
+  return PMD_OK;
+}
+
+// In place: C = U_c^T U_c (row-major lower triangle read) -> Et = U_c^{-T} (row-major lower, rest zeroed).
+size_t pmd_chol_inverse_workspace_bytes_impl(int m) { return ((size_t)m + CHOL_NB) * CHOL_NB * sizeof(float) + 8192; }
+
+int pmd_chol_inverse_impl(pmd_ctx* ctx, float* C, int m, long ldc, int* ok_host, void* ws, size_t ws_bytes) {
+  pmd_arena ar(ws, ws_bytes);
+  int* info = ar.take_n<int>(4);
+  float* chol_tmp = ar.take_n<float>((size_t)m * CHOL_NB);
+  float* chol_linv = ar.take_n<float>((size_t)CHOL_NB * CHOL_NB);
+  if (ar.overflow) return pmd_fail(ctx, PMD_ERR_WORKSPACE, "pmd_chol_inverse", "workspace too small");
+  *ok_host = 0;
   int hinfo = 0;
   {
     const char* cmode = getenv("PMD_CHOLESKY");
     if (cmode && !strcmp(cmode, "rocsolver")) {
       pmd_prof_scope prof__(ctx, "rocsolver_spotrf");
-      PMD_BLAS(ctx, rocsolver_spotrf(ctx->blas, rocblas_fill_upper, m, Et_out, (rocblas_int)lde, info));
+      PMD_BLAS(ctx, rocsolver_spotrf(ctx->blas, rocblas_fill_upper, m, C, (rocblas_int)ldc, info));
     } else {
-      RUN(chol_lower_rm(ctx, m, Et_out, lde, info, chol_tmp, chol_linv));
+      RUN(chol_lower_rm(ctx, m, C, ldc, info, chol_tmp, chol_linv));
     }
   }
   PMD_HIP(ctx, hipMemcpyAsync(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -977,14 +993,24 @@ int pmd_orthogonalize_chol_impl(pmd_ctx* ctx, const float* M, int Rc, int m, lon
   if (hinfo != 0) return PMD_OK;  // not positive definite: ok_host stays 0
   {
     pmd_prof_scope prof__(ctx, "rocsolver_strtri");
-    PMD_BLAS(ctx, rocsolver_strtri(ctx->blas, rocblas_fill_upper, rocblas_diagonal_non_unit, m, Et_out, (rocblas_int)lde, info));
+    PMD_BLAS(ctx, rocsolver_strtri(ctx->blas, rocblas_fill_upper, rocblas_diagonal_non_unit, m, C, (rocblas_int)ldc, info));
   }
   PMD_HIP(ctx, hipMemcpyAsync(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   // column-major upper U^{-1} == row-major lower U^{-T} = Et; clear the other triangle (old C entries)
-  hipLaunchKernelGGL(tril_mask_kernel, dim3(8, m), dim3(256), 0, ctx->stream, Et_out, lde, m);
+  hipLaunchKernelGGL(tril_mask_kernel, dim3(8, m), dim3(256), 0, ctx->stream, C, ldc, m);
   PMD_LAUNCH_CHECK(ctx, "tril_mask_kernel");
   PMD_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (hinfo != 0) return PMD_OK;
   *ok_host = 1;
   return PMD_OK;
+}
+
+int pmd_orthogonalize_chol_impl(pmd_ctx* ctx, const float* M, int Rc, int m, long ldm, const float* GM, long ldgm,
+                                float* Et_out, long lde, int* ok_host, void* ws, size_t ws_bytes) {
+  RUN(pmd_gram_mtgm_impl(ctx, M, Rc, m, ldm, GM, ldgm, Et_out, lde, ws, ws_bytes));
+  return pmd_chol_inverse_impl(ctx, Et_out, m, lde, ok_host, ws, ws_bytes);
+}
+
+int pmd_transpose_impl(pmd_ctx* ctx, const float* src, long lds_, int rows, int cols, float* dst, long ldd) {
+  return launch_transpose(ctx, src, lds_, rows, cols, dst, ldd);
 }

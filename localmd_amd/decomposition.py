@@ -579,6 +579,8 @@ def localmd_decomposition(
         _dbg("v_cropped", vc)
         P_dev = Et_dev = None
         chol_ok = False
+        shard = False               # rows of right / GM / Z / R split over the ranks (Cholesky route only)
+        row_lo, row_hi = 0, Rc
         if use_right:
             # P = right E / sqrt(lambda) stays factored; G = U^T U stays block-sparse
             n_pairs = pairs.shape[0]
@@ -594,10 +596,21 @@ def localmd_decomposition(
             GM = torch.empty((Rc, m_cols), dtype=torch.float32, device=ctx.device)
             Et_dev = torch.empty((m_cols, m_cols), dtype=torch.float32, device=ctx.device)
 
+            # Rows of `right`, GM, Z and R owned by this rank: the components of its tile run; the last rank
+            # also owns the K background rows.  Single process: everything.
+            row_lo, row_hi = int(offsets[t_lo]), int(offsets[t_hi])
+            if dist.rank == dist.world - 1:
+                row_hi = Rc
+            shard = dist.enabled
+
             def gram_apply(ncols):
-                ctx.call("pmd_gram_apply", ptr(gblk), ptr(gbg), ptr(gstrip), Rc, ptr(nbr_ptr_dev), ptr(nbr_dev),
-                         ptr(col_off_dev), ptr(ranks_dev), n_tiles, Rt, max(K, 0), int(ranks.max()) if n_tiles else 0,
-                         ptr(right), ld_right, ncols, ptr(GM), m_cols)
+                # block rows of G M for the tiles of this rank (all tiles when not distributed); the K background
+                # rows come from one small GEMM inside the call (every rank forms them, only their owner uses them)
+                if n_loc > 0 or not shard:
+                    a0, an = (t_lo, n_loc) if shard else (0, n_tiles)
+                    ctx.call("pmd_gram_apply", ptr(gblk), ptr(gbg), ptr(gstrip), Rc, ptr(nbr_ptr_dev[a0:]), ptr(nbr_dev),
+                             ptr(col_off_dev[a0:]), ptr(ranks_dev[a0:]), an, Rt, max(K, 0),
+                             int(ranks.max()) if n_tiles else 0, ptr(right), ld_right, ncols, ptr(GM), m_cols)
 
             chol_ok = False
             if orthogonalizer in ("auto", "cholesky"):
@@ -617,9 +630,22 @@ def localmd_decomposition(
                     m_eff = m_cols - 1
                 gram_apply(m_eff)
                 ok_c = c_i(0)
-                ws = ctx.workspace(lib.pmd_orthogonalize_chol_workspace_bytes(Rc, m_eff))
-                ctx.call("pmd_orthogonalize_chol", ptr(right), Rc, m_eff, ld_right, ptr(GM), m_cols, ptr(Et_dev), m_cols,
-                         C.byref(ok_c), ptr(ws), ws.numel())
+                if shard:
+                    # C = sum over ranks of right[rows]^T GM[rows]: one all-reduce of the m x m matrix, then the
+                    # (replicated) Cholesky step
+                    Et_dev.zero_()
+                    nrow = row_hi - row_lo
+                    if nrow > 0:
+                        ws = ctx.workspace(lib.pmd_gram_mtgm_workspace_bytes(nrow, m_eff))
+                        ctx.call("pmd_gram_mtgm", ptr(right[row_lo:]), nrow, m_eff, ld_right, ptr(GM[row_lo:]), m_cols,
+                                 ptr(Et_dev), m_cols, ptr(ws), ws.numel())
+                    dist.all_reduce(Et_dev)
+                    ws = ctx.workspace(lib.pmd_chol_inverse_workspace_bytes(m_eff))
+                    ctx.call("pmd_chol_inverse", ptr(Et_dev), m_eff, m_cols, C.byref(ok_c), ptr(ws), ws.numel())
+                else:
+                    ws = ctx.workspace(lib.pmd_orthogonalize_chol_workspace_bytes(Rc, m_eff))
+                    ctx.call("pmd_orthogonalize_chol", ptr(right), Rc, m_eff, ld_right, ptr(GM), m_cols, ptr(Et_dev),
+                             m_cols, C.byref(ok_c), ptr(ws), ws.numel())
                 chol_ok = bool(ok_c.value)
                 if chol_ok:
                     rp = m_eff
@@ -627,6 +653,8 @@ def localmd_decomposition(
                 elif orthogonalizer == "cholesky":
                     raise PMDLibraryError("orthogonalizer='cholesky': U^T U restricted to the right matrix is not positive definite")
             if not chol_ok:
+                shard = False  # eigenvector route: replicated on every rank
+                row_lo, row_hi = 0, Rc
                 gram_apply(m_cols)
                 ws = ctx.workspace(lib.pmd_orthogonalize_factored_workspace_bytes(m_cols))
                 rp_c = c_i(0)
@@ -653,9 +681,13 @@ def localmd_decomposition(
         else:
             del v_dev
             proj = torch.empty((n_tiles, 64, ld_T), dtype=torch.float32, device=ctx.device)
-        ctx.call("pmd_tiles_project", ptr(xs_full), ld_T, T, ptr(pix_dev), n_tiles, d, ptr(uw_dev), dpad, ptr(proj), ld_T, 2)
+        shard = shard and use_right and chol_ok and rp <= T
+        a0, an = (t_lo, n_loc) if shard else (0, n_tiles)   # sharded: every rank projects its own tiles only
         Z = torch.zeros((Rc, T), dtype=torch.float32, device=ctx.device)
-        ctx.call("pmd_compact_rows", ptr(proj), ld_T, ptr(col_off_dev), ptr(ranks_dev), T, ptr(Z), T, n_tiles)
+        if an > 0:
+            ctx.call("pmd_tiles_project", ptr(xs_full), ld_T, T, ptr(pix_dev[a0:]), an, d, ptr(uw_dev[a0:]), dpad,
+                     ptr(proj[a0:]), ld_T, 2)
+            ctx.call("pmd_compact_rows", ptr(proj[a0:]), ld_T, ptr(col_off_dev[a0:]), ptr(ranks_dev[a0:]), T, ptr(Z), T, an)
         if K > 0:
             if all_frames:
                 Z[Rt:Rt + K, :] = pj_dev[:, :T]
@@ -683,36 +715,62 @@ def localmd_decomposition(
             s_out = torch.empty((nk,), dtype=torch.float32, device=ctx.device)
             Vt_out = torch.empty((nk, T), dtype=torch.float32, device=ctx.device)
             X1 = torch.empty((m_used, rp), dtype=torch.float32, device=ctx.device)
+            W1 = None
+            if shard:
+                # M^T Z = sum over ranks of right[rows]^T Z[rows] (one all-reduce); the m x m stage is replicated
+                W1 = torch.zeros((m_used, T), dtype=torch.float32, device=ctx.device)
+                nrow = row_hi - row_lo
+                if nrow > 0:
+                    Mt = torch.empty((m_used, nrow), dtype=torch.float32, device=ctx.device)
+                    ctx.call("pmd_transpose", ptr(right[row_lo:]), m_cols, nrow, m_used, ptr(Mt), nrow)
+                    ctx.call("pmd_gemm", 0, 0, m_used, T, nrow, 1.0, ptr(Mt), nrow, ptr(Z[row_lo:]), T, 0.0, ptr(W1), T)
+                    ctx.sync()
+                    del Mt
+                dist.all_reduce(W1)
             ws = ctx.workspace(lib.pmd_projected_svd_factored_workspace_bytes(Rc, m_used, rp, T))
             ctx.call("pmd_projected_svd_factored", ptr(right), Rc, m_used, m_cols, ptr(Et_dev), rp, m_cols, ptr(Z), T, T,
-                     None, nk, ptr(s_out), ptr(Vt_out), T, ptr(Vp), T, ptr(X1), ptr(ws), ws.numel())
+                     None, nk, ptr(s_out), ptr(Vt_out), T, ptr(Vp), T, ptr(X1), ptr(W1), ptr(ws), ws.numel())
             # R = right X1 in row blocks; s, Vt and every finished block go to the host on a side stream
             # while the next block is computed (2.6 GB of results, ~45 ms of PCIe time otherwise serial)
             main = torch.cuda.current_stream(ctx.device)
             side = _side_stream(ctx.device)
-            r_host = torch.empty((Rc + extra_row, nk), dtype=torch.float32, pin_memory=True)
-            s_host = torch.empty((nk,), dtype=torch.float32, pin_memory=True)
-            vt_host = torch.empty((nk, T), dtype=torch.float32, pin_memory=True)
-            if extra_row:
-                r_host[Rc:].zero_()
-            ev = torch.cuda.Event()
-            ev.record(main)
-            side.wait_event(ev)
-            with torch.cuda.stream(side):
-                s_host.copy_(s_out, non_blocking=True)
-                vt_host.copy_(Vt_out, non_blocking=True)
-            blk = max(1024, -(-Rc // 8 // 256) * 256)
-            for r0 in range(0, Rc, blk):
-                r1 = min(Rc, r0 + blk)
-                ctx.call("pmd_gemm", 0, 0, r1 - r0, nk, m_used, 1.0, ptr(right[r0:]), m_cols, ptr(X1), rp, 0.0,
-                         ptr(R_out[r0:]), nk)
+            root = dist.rank == 0
+            if root:
+                r_host = torch.empty((Rc + extra_row, nk), dtype=torch.float32, pin_memory=True)
+                s_host = torch.empty((nk,), dtype=torch.float32, pin_memory=True)
+                vt_host = torch.empty((nk, T), dtype=torch.float32, pin_memory=True)
+                if extra_row:
+                    r_host[Rc:].zero_()
                 ev = torch.cuda.Event()
                 ev.record(main)
                 side.wait_event(ev)
                 with torch.cuda.stream(side):
-                    r_host[r0:r1].copy_(R_out[r0:r1], non_blocking=True)
+                    s_host.copy_(s_out, non_blocking=True)
+                    vt_host.copy_(Vt_out, non_blocking=True)
+
+            def download(lo, hi):
+                ev = torch.cuda.Event()
+                ev.record(main)
+                side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    r_host[lo:hi].copy_(R_out[lo:hi], non_blocking=True)
+
+            r_lo, r_hi = (row_lo, row_hi) if shard else (0, Rc)
+            blk = max(1024, -(-Rc // 8 // 256) * 256)
+            for r0 in range(r_lo, r_hi, blk):
+                r1 = min(r_hi, r0 + blk)
+                ctx.call("pmd_gemm", 0, 0, r1 - r0, nk, m_used, 1.0, ptr(right[r0:]), m_cols, ptr(X1), rp, 0.0,
+                         ptr(R_out[r0:]), nk)
+                if root:
+                    download(r0, r1)
+            if shard:
+                # the other ranks' row blocks of R travel to rank 0 and are downloaded as they arrive
+                ctx.sync()
+                bounds = [(int(offsets[lo]), Rc if rr == dist.world - 1 else int(offsets[hi])) for rr, (lo, hi) in enumerate(runs)]
+                dist.gather_rows_to_root(R_out, bounds, on_block=download if root else None)
             side.synchronize()
-            hosts = (r_host.numpy(), s_host.numpy(), vt_host.numpy())
+            if root:
+                hosts = (r_host.numpy(), s_host.numpy(), vt_host.numpy())
         else:
             if P_dev is None:  # factored P with R' > T (rank_prune corner): materialise P = right Et^T
                 P_dev = torch.empty((Rc, m_cols), dtype=torch.float32, device=ctx.device)
@@ -731,7 +789,10 @@ def localmd_decomposition(
             u_r = scipy.sparse.csr_matrix((u_host[0].numpy(), u_host[1].numpy(), u_host[2].numpy().astype(np.int32)),
                                           shape=(D, R))
             u_pending = None
-        if hosts is not None:
+        root_only = shard and dist.rank != 0   # sharded global stage: the results live on rank 0
+        if root_only:
+            r_mat = s = vt = None
+        elif hosts is not None:
             r_mat, s, vt = hosts
         else:
             r_mat = _to_host(R_out)
@@ -739,17 +800,18 @@ def localmd_decomposition(
             vt = _to_host(Vt_out)
             if extra_row:
                 r_mat = np.concatenate([r_mat, np.zeros((1, r_mat.shape[1]), dtype=r_mat.dtype)], axis=0)
-        good_components = s != 0
-        if not np.all(good_components):
-            r_mat = r_mat[:, good_components]
-            s = s[good_components]
-            vt = vt[good_components, :]
+        if not root_only:
+            good_components = s != 0
+            if not np.all(good_components):
+                r_mat = r_mat[:, good_components]
+                s = s[good_components]
+                vt = vt[good_components, :]
         lap("d2h_results", t0)
         display("Matrix decomposition completed")
 
         mean_img = mean_dev.cpu().numpy().reshape(d1, d2)
         std_img = std_dev.cpu().numpy().reshape(d1, d2)
-        final_movie = PMDArray(u_r, r_mat, s, vt, (T, d1, d2), order, mean_img, std_img)
+        final_movie = None if root_only else PMDArray(u_r, r_mat, s, vt, (T, d1, d2), order, mean_img, std_img)
         timings["total"] = time.perf_counter() - t_start
         if not return_diagnostics:
             return final_movie

@@ -48,6 +48,48 @@ class Dist:
                 dist.broadcast(tensor[lo:hi], src=dist.get_global_rank(self.group, r) if self.group is not None else r,
                                group=self.group)
 
+    def all_reduce(self, tensor):
+        """In-place sum over the ranks (RCCL all-reduce on GPUs)."""
+        if not self.enabled:
+            return
+        import torch.distributed as dist
+
+        dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=self.group)
+
+    def gather_rows_to_root(self, tensor, bounds, on_block=None):
+        """Rank r has filled rows [bounds[r][0], bounds[r][1]) of ``tensor``; afterwards rank 0 holds all rows.
+        ``on_block(lo, hi)`` runs on rank 0 as each remote block has arrived (e.g. to start its download).
+        RCCL: point-to-point sends into rank 0, all receives posted at once; other backends (gloo cannot send
+        device tensors): one broadcast per owner."""
+        if not self.enabled:
+            return
+        import torch.distributed as dist
+
+        def grank(r):
+            return dist.get_global_rank(self.group, r) if self.group is not None else r
+
+        if dist.get_backend(self.group) == "nccl":
+            if self.rank == 0:
+                todo = [(r, lo, hi) for r, (lo, hi) in enumerate(bounds) if r != 0 and hi > lo]
+                ops = [dist.P2POp(dist.irecv, tensor[lo:hi], grank(r), self.group) for r, lo, hi in todo]
+                reqs = dist.batch_isend_irecv(ops) if ops else []
+                for req in reqs:
+                    req.wait()
+                for _, lo, hi in todo:
+                    if on_block is not None:
+                        on_block(lo, hi)
+            else:
+                lo, hi = bounds[self.rank]
+                if hi > lo:
+                    for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, tensor[lo:hi], grank(0), self.group)]):
+                        req.wait()
+        else:
+            for r, (lo, hi) in enumerate(bounds):
+                if r != 0 and hi > lo:
+                    dist.broadcast(tensor[lo:hi], src=grank(r), group=self.group)
+                    if self.rank == 0 and on_block is not None:
+                        on_block(lo, hi)
+
     def barrier(self):
         if self.enabled:
             import torch.distributed as dist

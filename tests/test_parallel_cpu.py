@@ -74,10 +74,54 @@ def test_gather_runs_world2_gloo(tmp_path):
         np.testing.assert_array_equal(g["vc"], exp_vc)
 
 
+def _worker_global(rank, world, port, out_dir):
+    """The exchange steps of the row-sharded global stage: partial Gram matrices summed over the ranks, row blocks
+    of R collected on rank 0 (with the per-block callback the host driver uses to start downloads)."""
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        d = Dist(True)
+        rng = np.random.default_rng(0)
+        M = torch.from_numpy(rng.standard_normal((23, 7)).astype(np.float32))   # same on every rank
+        bounds = [(0, 9), (9, 23)] if world == 2 else [(0, 5), (5, 5), (5, 23)]
+        lo, hi = bounds[rank]
+        C = M[lo:hi].T @ M[lo:hi]            # partial M^T M of this rank's rows
+        d.all_reduce(C)
+        R = torch.zeros((23, 3), dtype=torch.float32)
+        R[lo:hi] = M[lo:hi, :3] * 2.0
+        seen = []
+        d.gather_rows_to_root(R, bounds, on_block=(lambda a, b: seen.append((a, b))) if rank == 0 else None)
+        d.barrier()
+        np.savez(os.path.join(out_dir, f"g{rank}.npz"), C=C.numpy(), R=R.numpy(), M=M.numpy(), seen=np.array(seen).reshape(-1, 2))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_global_stage_exchanges_gloo(tmp_path, world):
+    import torch.multiprocessing as mp
+
+    port = _free_port()
+    mp.spawn(_worker_global, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    got = [np.load(tmp_path / f"g{r}.npz") for r in range(world)]
+    M = got[0]["M"]
+    for g in got:
+        np.testing.assert_allclose(g["C"], M.T @ M, rtol=1e-5, atol=1e-5)
+    np.testing.assert_array_equal(got[0]["R"], M[:, :3] * 2.0)       # rank 0 holds every row
+    expected_blocks = [(9, 23)] if world == 2 else [(5, 23)]         # empty runs are skipped
+    assert [tuple(x) for x in got[0]["seen"].tolist()] == expected_blocks
+
+
 def test_single_process_dist_is_a_noop():
     d = Dist(False)
     assert (d.rank, d.world, d.enabled) == (0, 1, False)
     d.gather_runs(None, [(0, 1)])
+    d.all_reduce(None)
+    d.gather_rows_to_root(None, [(0, 1)])
     d.barrier()
     with pytest.raises(RuntimeError):
         Dist(True)
