@@ -352,8 +352,17 @@ int pmd_projected_svd_impl(pmd_ctx* ctx, const float* P, int rows_p, long ldp, c
   int* info = ar.take_n<int>(4);
   float* left = (n1 > n2) ? ar.take_n<float>((size_t)n1 * n2) : nullptr;
   if (ar.overflow) return pmd_fail(ctx, PMD_ERR_WORKSPACE, "pmd_projected_svd", "workspace too small");
-  if (n1 <= n2) RUN(pmd_gemm_rm(ctx, 0, 1, n1, n1, n2, 1.f, V, ldv, V, ldv, 0.f, C, ldc));  // V V^T
-  else RUN(pmd_gemm_rm(ctx, 1, 0, n2, n2, n1, 1.f, V, ldv, V, ldv, 0.f, C, ldc));           // V^T V
+  {
+    // Gram matrix: only the row-major upper triangle (= column-major lower), the one pmd_syevd reads
+    pmd_prof_scope prof__(ctx, "rocblas_ssyrk");
+    const float one = 1.f, zero = 0.f;
+    if (n1 <= n2)  // V V^T
+      PMD_BLAS(ctx, rocblas_ssyrk(ctx->blas, rocblas_fill_lower, rocblas_operation_transpose, n1, n2, &one, V, (rocblas_int)ldv,
+                                  &zero, C, (rocblas_int)ldc));
+    else           // V^T V
+      PMD_BLAS(ctx, rocblas_ssyrk(ctx->blas, rocblas_fill_lower, rocblas_operation_none, n2, n1, &one, V, (rocblas_int)ldv,
+                                  &zero, C, (rocblas_int)ldc));
+  }
   RUN(pmd_syevd(ctx, nk, C, ldc, w, work, info));
   std::vector<float> hw(nk);
   int hinfo = 0;

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void small_eig_kernel(const double* __restrict
             const double t = ((th >= 0.0) ? 1.0 : -1.0) / (fabs(th) + sqrt(1.0 + th * th));
             c = 1.0 / sqrt(1.0 + t * t);
             s = t * c;
-            if (fabs(apq) > 1e-14 * sqrt(fabs(app * aqq))) flag[0] = 1;
+            if (fabs(apq) > 1e-12 * sqrt(fabs(app * aqq))) flag[0] = 1;
           }
         }
         cs[2 * tid] = c; cs[2 * tid + 1] = s;

@@ -613,7 +613,7 @@ int pmd_sytrd_auto(pmd_ctx* ctx, int n, float* A, long lda, float* d, float* e, 
 }
 
 // Symmetric eigendecomposition, ascending eigenvalues; on exit memory row j of A is eigenvector j.
-// A must hold the full symmetric matrix.  work: n floats, info: device int.
+// Only the row-major upper triangle of A (= column-major lower) is read.  work: n floats, info: device int.
 int pmd_syevd(pmd_ctx* ctx, int n, float* A, long lda, float* w, float* work, int* info) {
   const char* mode = getenv("PMD_SYEVD");
   const bool force_lib = mode && !strcmp(mode, "rocsolver");
@@ -621,7 +621,7 @@ int pmd_syevd(pmd_ctx* ctx, int n, float* A, long lda, float* w, float* work, in
   const bool own = !force_lib && (force_own || n >= 1024) && n >= 3 && lda % 4 == 0 && lda >= pmd_round_up(n, 4) && !((uintptr_t)A & 15);
   if (!own) {
     pmd_prof_scope prof__(ctx, "rocsolver_ssyevd");
-    PMD_BLAS(ctx, rocsolver_ssyevd(ctx->blas, rocblas_evect_original, rocblas_fill_upper, n, A, (rocblas_int)lda, w, work, info));
+    PMD_BLAS(ctx, rocsolver_ssyevd(ctx->blas, rocblas_evect_original, rocblas_fill_lower, n, A, (rocblas_int)lda, w, work, info));
     return PMD_OK;
   }
   const size_t tb = std::max(pmd_sytrd_workspace_bytes_impl(n), pmd_apply_q_workspace_bytes_impl(n));
