@@ -251,6 +251,7 @@ __global__ __launch_bounds__(256) void filter_kernel(const float* __restrict__ i
   const long f = (long)blockIdx.x * 256 + threadIdx.x;
   const long c0 = (long)blockIdx.y * 64;
   const bool live = f < nf;
+  const bool pad = !live && f < ld;   // padding columns [nf, ld) are written as zeros (consumers read whole rows)
   const long fc = live ? f : nf - 1;
   // loads are unconditional (clamped index, masked value): a guarded load compiles to a branch with a full wait
   float p[KMAX];
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(256) void filter_kernel(const float* __restrict__ i
       float acc = 0.f;
 #pragma unroll
       for (int k = 0; k < KMAX; ++k) acc = fmaf(b[(k < K) ? k : 0], p[k], acc);
-      if (live && c + u < c1) out[cu * ld + f] = v[u] - acc;
+      if ((live || pad) && c + u < c1) out[cu * ld + f] = live ? v[u] - acc : 0.f;
     }
   }
 }
@@ -280,7 +281,7 @@ int pmd_launch_filter(pmd_ctx* ctx, const float* in, float* out, long D, int nf,
                       const float* pj, long ldp) {
   pmd_prof_scope prof__(ctx, "bg_filter");
   if (K > 64) return pmd_fail(ctx, PMD_ERR_UNSUPPORTED, "pmd_filter", "background rank > 64");
-  const int bx = (nf + 255) / 256;
+  const int bx = (int)((ld + 255) / 256);
   const long rows_per_launch = 65535L * 64;
   for (long c0 = 0; c0 < D; c0 += rows_per_launch) {
     const long cn = (D - c0 < rows_per_launch) ? D - c0 : rows_per_launch;

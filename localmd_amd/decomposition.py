@@ -104,7 +104,10 @@ class _Movie:
         ctx = self.ctx
         nf = self.T if frames is None else len(frames)
         ld = ctx.lib.pmd_time_ld(nf)
-        out = torch.zeros((self.rows_alloc, ld), dtype=torch.float32, device=ctx.device)
+        # the kernel writes every column of the D pixel rows (zeros beyond nf); only the row padding needs a fill
+        out = torch.empty((self.rows_alloc, ld), dtype=torch.float32, device=ctx.device)
+        if self.rows_alloc > self.D:
+            out[self.D:].zero_()
         fr = None if frames is None else _i32(ctx, frames)
         ctx.call("pmd_standardize_transpose", ptr(self.dev), self.D, ptr(fr), nf, ptr(mean), ptr(std), ptr(out), ld)
         return out, ld
@@ -382,7 +385,9 @@ def localmd_decomposition(
             pj_dev = torch.zeros((K, ld_f), dtype=torch.float32, device=ctx.device)
             ws = ctx.workspace(lib.pmd_bg_project_workspace_bytes(D, Tf))
             ctx.call("pmd_bg_project", ptr(xs_init), D, Tf, ld_f, ptr(basis_dev), K, ptr(pj_dev), ld_f, ptr(ws), ws.numel())
-            xf = torch.zeros_like(xs_init)
+            xf = torch.empty_like(xs_init)   # bg_filter writes all ld columns of the D pixel rows
+            if xf.shape[0] > D:
+                xf[D:].zero_()
             ctx.call("pmd_bg_filter", ptr(xs_init), ptr(xf), D, Tf, ld_f, ptr(basis_dev), K, ptr(pj_dev), ld_f)
         else:
             xf = xs_init.clone() if pixel_weighting is not None else xs_init
