@@ -137,8 +137,26 @@ class Context:
             raise PMDLibraryError(f"pmd_ctx_create failed with code {rc}")
         self.handle = handle
         self._ws = None
+        self._side = None
+
+    def side(self):
+        """A second context on its own HIP stream (``.stream``) for work that may overlap the main stream's
+        (e.g. the latency-bound Cholesky step next to a large GEMM).  Created on first use, closed with self."""
+        import torch
+
+        if self._side is None:
+            # high priority: its short kernels should slip in between the workgroups of a large GEMM on the main stream
+            st = torch.cuda.Stream(device=self.device, priority=-1)
+            with torch.cuda.stream(st):
+                sc = Context(self.device_index)
+            sc.stream = st
+            self._side = sc
+        return self._side
 
     def close(self):
+        if getattr(self, "_side", None) is not None:
+            self._side.close()
+            self._side = None
         if getattr(self, "handle", None):
             self.lib.pmd_ctx_destroy(self.handle)
             self.handle = None
@@ -186,3 +204,5 @@ class Context:
 
     def release_workspace(self):
         self._ws = None
+        if getattr(self, "_side", None) is not None:
+            self._side._ws = None

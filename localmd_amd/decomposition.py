@@ -586,6 +586,31 @@ def localmd_decomposition(
         chol_ok = False
         shard = False               # rows of right / GM / Z / R split over the ranks (Cholesky route only)
         row_lo, row_hi = 0, Rc
+        Z = W1 = None
+
+        def build_z(a0, an):
+            """Z = (U W)^T ((Y - mean) / std) over the whole movie for tiles [a0, a0 + an) (pmd_loader.py:316-346);
+            the K background rows are always filled."""
+            if all_frames and ldv == ld_T:
+                proj = v_dev     # same shape; the fit-frame traces are already compacted into v_cropped
+            else:
+                proj = torch.empty((n_tiles, 64, ld_T), dtype=torch.float32, device=ctx.device)
+            z = torch.zeros((Rc, T), dtype=torch.float32, device=ctx.device)
+            if an > 0:
+                ctx.call("pmd_tiles_project", ptr(xs_full), ld_T, T, ptr(pix_dev[a0:]), an, d, ptr(uw_dev[a0:]), dpad,
+                         ptr(proj[a0:]), ld_T, 2)
+                ctx.call("pmd_compact_rows", ptr(proj[a0:]), ld_T, ptr(col_off_dev[a0:]), ptr(ranks_dev[a0:]), T, ptr(z), T, an)
+            if K > 0:
+                if all_frames:
+                    z[Rt:Rt + K, :] = pj_dev[:, :T]
+                else:
+                    pj_full = torch.zeros((K, ld_T), dtype=torch.float32, device=ctx.device)
+                    ws_ = ctx.workspace(lib.pmd_bg_project_workspace_bytes(D, T))
+                    ctx.call("pmd_bg_project", ptr(xs_full), D, T, ld_T, ptr(basis_dev), K, ptr(pj_full), ld_T, ptr(ws_),
+                             ws_.numel())
+                    z[Rt:Rt + K, :] = pj_full[:, :T]
+            return z
+
         if use_right:
             # P = right E / sqrt(lambda) stays factored; G = U^T U stays block-sparse
             n_pairs = pairs.shape[0]
@@ -635,23 +660,46 @@ def localmd_decomposition(
                     m_eff = m_cols - 1
                 gram_apply(m_eff)
                 ok_c = c_i(0)
+                # C = right[rows]^T GM[rows] (summed over the ranks when the rows are sharded)
                 if shard:
-                    # C = sum over ranks of right[rows]^T GM[rows]: one all-reduce of the m x m matrix, then the
-                    # (replicated) Cholesky step
                     Et_dev.zero_()
-                    nrow = row_hi - row_lo
-                    if nrow > 0:
-                        ws = ctx.workspace(lib.pmd_gram_mtgm_workspace_bytes(nrow, m_eff))
-                        ctx.call("pmd_gram_mtgm", ptr(right[row_lo:]), nrow, m_eff, ld_right, ptr(GM[row_lo:]), m_cols,
-                                 ptr(Et_dev), m_cols, ptr(ws), ws.numel())
-                    dist.all_reduce(Et_dev)
-                    ws = ctx.workspace(lib.pmd_chol_inverse_workspace_bytes(m_eff))
-                    ctx.call("pmd_chol_inverse", ptr(Et_dev), m_eff, m_cols, C.byref(ok_c), ptr(ws), ws.numel())
-                else:
-                    ws = ctx.workspace(lib.pmd_orthogonalize_chol_workspace_bytes(Rc, m_eff))
-                    ctx.call("pmd_orthogonalize_chol", ptr(right), Rc, m_eff, ld_right, ptr(GM), m_cols, ptr(Et_dev),
-                             m_cols, C.byref(ok_c), ptr(ws), ws.numel())
+                nrow = row_hi - row_lo
+                if nrow > 0:
+                    ws = ctx.workspace(lib.pmd_gram_mtgm_workspace_bytes(nrow, m_eff))
+                    ctx.call("pmd_gram_mtgm", ptr(right[row_lo:]), nrow, m_eff, ld_right, ptr(GM[row_lo:]), m_cols,
+                             ptr(Et_dev), m_cols, ptr(ws), ws.numel())
+                dist.all_reduce(Et_dev)
+                # The Cholesky step (C -> Et) is a chain of small latency-bound launches; the V projection
+                # Z = (UW)^T Y and the large product M^T Z do not depend on it.  Those are enqueued on the main
+                # stream first, then the Cholesky step runs on a second stream next to them.
+                main = torch.cuda.current_stream(ctx.device)
+                ev_c = torch.cuda.Event()
+                ev_c.record(main)
+                lap("orthogonalize", t0)
+                t0 = time.perf_counter()
+                Z = build_z(t_lo, n_loc) if shard else build_z(0, n_tiles)
+                W1 = torch.zeros((m_eff, T), dtype=torch.float32, device=ctx.device)
+                if nrow > 0:
+                    Mt = torch.empty((m_eff, nrow), dtype=torch.float32, device=ctx.device)
+                    ctx.call("pmd_transpose", ptr(right[row_lo:]), m_cols, nrow, m_eff, ptr(Mt), nrow)
+                    ctx.call("pmd_gemm", 0, 0, m_eff, T, nrow, 1.0, ptr(Mt), nrow, ptr(Z[row_lo:]), T, 0.0, ptr(W1), T)
+                lap("v_projection", t0)
+                t0 = time.perf_counter()
+                sc = ctx.side()
+                sc.stream.wait_event(ev_c)
+                with torch.cuda.stream(sc.stream):
+                    ws2 = sc.workspace(lib.pmd_chol_inverse_workspace_bytes(m_eff))
+                    sc.call("pmd_chol_inverse", ptr(Et_dev), m_eff, m_cols, C.byref(ok_c), ptr(ws2), ws2.numel())
+                    ev_e = torch.cuda.Event()
+                    ev_e.record(sc.stream)
+                main.wait_event(ev_e)
+                ctx.sync()
+                Mt = None
                 chol_ok = bool(ok_c.value)
+                if chol_ok:
+                    dist.all_reduce(W1)
+                else:
+                    Z = W1 = None   # eigenvector route below: full Z, M^T Z inside pmd_projected_svd_factored
                 if chol_ok:
                     rp = m_eff
                     m_used = m_eff
@@ -678,29 +726,12 @@ def localmd_decomposition(
         display("After performing rank reduction, the updated rank is {}".format(rp))
         lap("orthogonalize", t0)
 
-        # ---- V = P^T U^T X over the whole movie (pmd_loader.py:316-346)
+        # ---- V = P^T U^T X over the whole movie (pmd_loader.py:316-346); already enqueued on the Cholesky route
         display("Running sparse regression")
         t0 = time.perf_counter()
-        if all_frames and ldv == ld_T:
-            proj = v_dev
-        else:
-            del v_dev
-            proj = torch.empty((n_tiles, 64, ld_T), dtype=torch.float32, device=ctx.device)
         shard = shard and use_right and chol_ok and rp <= T
-        a0, an = (t_lo, n_loc) if shard else (0, n_tiles)   # sharded: every rank projects its own tiles only
-        Z = torch.zeros((Rc, T), dtype=torch.float32, device=ctx.device)
-        if an > 0:
-            ctx.call("pmd_tiles_project", ptr(xs_full), ld_T, T, ptr(pix_dev[a0:]), an, d, ptr(uw_dev[a0:]), dpad,
-                     ptr(proj[a0:]), ld_T, 2)
-            ctx.call("pmd_compact_rows", ptr(proj[a0:]), ld_T, ptr(col_off_dev[a0:]), ptr(ranks_dev[a0:]), T, ptr(Z), T, an)
-        if K > 0:
-            if all_frames:
-                Z[Rt:Rt + K, :] = pj_dev[:, :T]
-            else:
-                pj_full = torch.zeros((K, ld_T), dtype=torch.float32, device=ctx.device)
-                ws = ctx.workspace(lib.pmd_bg_project_workspace_bytes(D, T))
-                ctx.call("pmd_bg_project", ptr(xs_full), D, T, ld_T, ptr(basis_dev), K, ptr(pj_full), ld_T, ptr(ws), ws.numel())
-                Z[Rt:Rt + K, :] = pj_full[:, :T]
+        if Z is None:
+            Z = build_z(0, n_tiles)
         _dbg("Z", Z)
         lap("v_projection", t0)
 
@@ -720,18 +751,8 @@ def localmd_decomposition(
             s_out = torch.empty((nk,), dtype=torch.float32, device=ctx.device)
             Vt_out = torch.empty((nk, T), dtype=torch.float32, device=ctx.device)
             X1 = torch.empty((m_used, rp), dtype=torch.float32, device=ctx.device)
-            W1 = None
-            if shard:
-                # M^T Z = sum over ranks of right[rows]^T Z[rows] (one all-reduce); the m x m stage is replicated
-                W1 = torch.zeros((m_used, T), dtype=torch.float32, device=ctx.device)
-                nrow = row_hi - row_lo
-                if nrow > 0:
-                    Mt = torch.empty((m_used, nrow), dtype=torch.float32, device=ctx.device)
-                    ctx.call("pmd_transpose", ptr(right[row_lo:]), m_cols, nrow, m_used, ptr(Mt), nrow)
-                    ctx.call("pmd_gemm", 0, 0, m_used, T, nrow, 1.0, ptr(Mt), nrow, ptr(Z[row_lo:]), T, 0.0, ptr(W1), T)
-                    ctx.sync()
-                    del Mt
-                dist.all_reduce(W1)
+            # W1 = M^T Z was formed next to the Cholesky step (summed over the ranks when the rows are sharded);
+            # None on the eigenvector route (formed inside the call)
             ws = ctx.workspace(lib.pmd_projected_svd_factored_workspace_bytes(Rc, m_used, rp, T))
             ctx.call("pmd_projected_svd_factored", ptr(right), Rc, m_used, m_cols, ptr(Et_dev), rp, m_cols, ptr(Z), T, T,
                      None, nk, ptr(s_out), ptr(Vt_out), T, ptr(Vp), T, ptr(X1), ptr(W1), ptr(ws), ws.numel())
@@ -761,7 +782,9 @@ def localmd_decomposition(
                     r_host[lo:hi].copy_(R_out[lo:hi], non_blocking=True)
 
             r_lo, r_hi = (row_lo, row_hi) if shard else (0, Rc)
-            blk = max(1024, -(-Rc // 8 // 256) * 256)
+            import os as _os
+            n_blk = max(1, int(_os.environ.get("PMD_R_BLOCKS", "4")))
+            blk = max(1024, -(-(r_hi - r_lo) // n_blk))
             for r0 in range(r_lo, r_hi, blk):
                 r1 = min(r_hi, r0 + blk)
                 ctx.call("pmd_gemm", 0, 0, r1 - r0, nk, m_used, 1.0, ptr(right[r0:]), m_cols, ptr(X1), rp, 0.0,
