@@ -164,11 +164,12 @@ size_t pmd_orthogonalize_chol_workspace_bytes(int Rc, int m);
 size_t pmd_projected_svd_factored_workspace_bytes(int Rc, int m, int rp, int T);
 int pmd_projected_svd_factored(pmd_ctx* ctx, const float* M, int Rc, int m, long ldm, const float* Et, int rp, long lde,
                                const float* Z, int T, long ldz, float* R_out, long ldr, float* s_out, float* Vt_out,
-                               long ldvt, float* Vp_out, long ldvp, float* X1_out, const float* W1_in, void* ws,
-                               size_t ws_bytes);
+                               long ldvt, float* Vp_out, long ldvp, float* X1_out, const float* W1_in, int et_lower,
+                               void* ws, size_t ws_bytes);
 /* (X1_out: optional m x rp, ld rp, receives Et^T W.  With R_out == NULL the last product R = M X1 is left to the
  * caller, who can then form R in row blocks with pmd_gemm and overlap their download with the next block.
- * W1_in: optional m x T, ld T: M^T Z formed by the caller, e.g. the all-reduced sum of per-rank row-range partials.) */
+ * W1_in: optional m x T, ld T: M^T Z formed by the caller, e.g. the all-reduced sum of per-rank row-range partials.
+ * et_lower != 0: Et is square lower triangular (pmd_orthogonalize_chol / pmd_chol_inverse), strmm replaces two GEMMs.) */
 /* The two halves of pmd_orthogonalize_chol, for callers that shard the rows of M over ranks: the partial
  * C = M[rows]^T GM[rows] (row-major lower block triangle; all-reduce it), then C -> Et in place. */
 size_t pmd_gram_mtgm_workspace_bytes(int rows, int m);

@@ -297,11 +297,11 @@ size_t pmd_projected_svd_factored_workspace_bytes(int Rc, int m, int rp, int T) 
 }
 int pmd_projected_svd_factored(pmd_ctx* ctx, const float* M, int Rc, int m, long ldm, const float* Et, int rp, long lde,
                                const float* Z, int T, long ldz, float* R_out, long ldr, float* s_out, float* Vt_out,
-                               long ldvt, float* Vp_out, long ldvp, float* X1_out, const float* W1_in, void* ws,
-                               size_t ws_bytes) {
+                               long ldvt, float* Vp_out, long ldvp, float* X1_out, const float* W1_in, int et_lower,
+                               void* ws, size_t ws_bytes) {
   CTX_CHECK(ctx);
   return pmd_projected_svd_factored_impl(ctx, M, Rc, m, ldm, Et, rp, lde, Z, T, ldz, R_out, ldr, s_out, Vt_out, ldvt,
-                                         Vp_out, ldvp, X1_out, W1_in, ws, ws_bytes);
+                                         Vp_out, ldvp, X1_out, W1_in, et_lower, ws, ws_bytes);
 }
 
 // ---- kernel-level entry points ---------------------------------------------------------------

@@ -804,7 +804,7 @@ size_t pmd_projected_svd_factored_workspace_bytes_impl(int Rc, int m, int rp, in
 int pmd_projected_svd_factored_impl(pmd_ctx* ctx, const float* M, int Rc, int m, long ldm, const float* Et, int rp,
                                     long lde, const float* Z, int T, long ldz, float* R_out, long ldr, float* s_out,
                                     float* Vt_out, long ldvt, float* Vp_out, long ldvp, float* X1_out,
-                                    const float* W1_in, void* ws, size_t ws_bytes) {
+                                    const float* W1_in, int et_lower, void* ws, size_t ws_bytes) {
   if (rp > T) return pmd_fail(ctx, PMD_ERR_UNSUPPORTED, "pmd_projected_svd_factored", "needs R' <= T");
   pmd_arena ar(ws, ws_bytes);
   float* W1 = ar.take_n<float>((size_t)m * T);
@@ -823,12 +823,29 @@ int pmd_projected_svd_factored_impl(pmd_ctx* ctx, const float* M, int Rc, int m,
     RUN(pmd_gemm_rm(ctx, 0, 0, m, T, Rc, 1.f, Mt, Rc, Z, ldz, 0.f, W1, T));      // M^T Z
   }
   // (W1_in: the caller has formed M^T Z already, e.g. as an all-reduced sum of per-rank row-range partials)
-  RUN(pmd_gemm_rm(ctx, 0, 0, rp, T, m, 1.f, Et, lde, W1_in ? W1_in : W1, T, 0.f, Vp, ldv));     // V = Et (M^T Z)
+  const bool tri = et_lower && rp == m;  // Cholesky route: Et is lower triangular, strmm does half the work
+  const float one = 1.f;
+  if (tri) {
+    // row-major Vp = Et W1  <=>  column-major Vp^T = W1^T Et^T with Et^T upper on the right
+    pmd_prof_scope prof__(ctx, "rocblas_strmm");
+    PMD_BLAS(ctx, rocblas_strmm(ctx->blas, rocblas_side_right, rocblas_fill_upper, rocblas_operation_none,
+                                rocblas_diagonal_non_unit, T, m, &one, Et, (rocblas_int)lde, W1_in ? W1_in : W1, T, Vp,
+                                (rocblas_int)ldv));
+  } else {
+    RUN(pmd_gemm_rm(ctx, 0, 0, rp, T, m, 1.f, Et, lde, W1_in ? W1_in : W1, T, 0.f, Vp, ldv));     // V = Et (M^T Z)
+  }
   // SVD of V with the identity as projection: the "R" it returns is W (rp x rp), reuse W1's memory
   float* Wmat = W1;  // rp x rp  (rp <= m, T)
   RUN(pmd_projected_svd_impl(ctx, nullptr, 0, 0, Vp, rp, T, ldv, Wmat, rp, s_out, Vt_out, ldvt, sub, sub_bytes));
   // R = M (Et^T W)
-  RUN(pmd_gemm_rm(ctx, 1, 0, m, rp, rp, 1.f, Et, lde, Wmat, rp, 0.f, X1, rp));
+  if (tri) {
+    // row-major X1 = Et^T W  <=>  column-major X1^T = W^T (Et^T)^T
+    pmd_prof_scope prof__(ctx, "rocblas_strmm");
+    PMD_BLAS(ctx, rocblas_strmm(ctx->blas, rocblas_side_right, rocblas_fill_upper, rocblas_operation_transpose,
+                                rocblas_diagonal_non_unit, rp, m, &one, Et, (rocblas_int)lde, Wmat, rp, X1, rp));
+  } else {
+    RUN(pmd_gemm_rm(ctx, 1, 0, m, rp, rp, 1.f, Et, lde, Wmat, rp, 0.f, X1, rp));
+  }
   if (R_out) RUN(pmd_gemm_rm(ctx, 0, 0, Rc, rp, m, 1.f, M, ldm, X1, rp, 0.f, R_out, ldr));
   return PMD_OK;
 }

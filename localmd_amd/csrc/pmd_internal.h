@@ -111,7 +111,7 @@ size_t pmd_orthogonalize_chol_workspace_bytes_impl(int Rc, int m);
 int pmd_projected_svd_factored_impl(pmd_ctx* ctx, const float* M, int Rc, int m, long ldm, const float* Et, int rp,
                                     long lde, const float* Z, int T, long ldz, float* R_out, long ldr, float* s_out,
                                     float* Vt_out, long ldvt, float* Vp_out, long ldvp, float* X1_out,
-                                    const float* W1_in, void* ws, size_t ws_bytes);
+                                    const float* W1_in, int et_lower, void* ws, size_t ws_bytes);
 size_t pmd_gram_mtgm_workspace_bytes_impl(int rows, int m);
 int pmd_gram_mtgm_impl(pmd_ctx* ctx, const float* M, int rows, int m, long ldm, const float* GM, long ldgm, float* C,
                        long ldc, void* ws, size_t ws_bytes);

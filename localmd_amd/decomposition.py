@@ -755,7 +755,8 @@ def localmd_decomposition(
             # None on the eigenvector route (formed inside the call)
             ws = ctx.workspace(lib.pmd_projected_svd_factored_workspace_bytes(Rc, m_used, rp, T))
             ctx.call("pmd_projected_svd_factored", ptr(right), Rc, m_used, m_cols, ptr(Et_dev), rp, m_cols, ptr(Z), T, T,
-                     None, nk, ptr(s_out), ptr(Vt_out), T, ptr(Vp), T, ptr(X1), ptr(W1), ptr(ws), ws.numel())
+                     None, nk, ptr(s_out), ptr(Vt_out), T, ptr(Vp), T, ptr(X1), ptr(W1), 1 if chol_ok else 0, ptr(ws),
+                     ws.numel())
             # R = right X1 in row blocks; s, Vt and every finished block go to the host on a side stream
             # while the next block is computed (2.6 GB of results, ~45 ms of PCIe time otherwise serial)
             main = torch.cuda.current_stream(ctx.device)
