@@ -134,7 +134,8 @@ int pmd_launch_small_qr(pmd_ctx* ctx, const float* Yt, long y_tile_stride, int y
 //   mode 1: column c scaled by 1/sqrt(lambda_c); columns with lambda_c <= tol*lambda_max zeroed
 // lam_out[tile][c] = eigenvalue c (descending); entries >= n are zero.
 #define EIG_LD 65
-__global__ __launch_bounds__(256) void small_eig_kernel(const double* __restrict__ G, long g_tile_stride, int slices,
+#define EIG_THREADS 1024  // one 2x2 block of the rotation step per thread at n = 60: the step is latency bound
+__global__ __launch_bounds__(EIG_THREADS) void small_eig_kernel(const double* __restrict__ G, long g_tile_stride, int slices,
                                                         int n, int mode, double tol, double* __restrict__ Nout,
                                                         double* __restrict__ lam_out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(256) void small_eig_kernel(const double* __restrict
   int* order = flag + 2;                        // [64]
   const int tid = threadIdx.x;
   const double* g = G + (long)blockIdx.x * g_tile_stride;
-  for (int i = tid; i < 64 * 64; i += 256) {
+  for (int i = tid; i < 64 * 64; i += EIG_THREADS) {
     const int r = i >> 6, c = i & 63;
     double s = 0.0;
     if (r < n && c < n)
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(256) void small_eig_kernel(const double* __restrict
       __syncthreads();
       // A <- J^T A J in one pass: the 2x2 block (pair k rows) x (pair k' columns) gets both rotations;
       // blocks are disjoint, so one barrier per step suffices.  V <- V J rides in the same phase.
-      for (int i = tid; i < half * half; i += 256) {
+      for (int i = tid; i < half * half; i += EIG_THREADS) {
         const int k = i / half, kp = i - k * half;
         const double c = cs[2 * k], s = cs[2 * k + 1], c2 = cs[2 * kp], s2 = cs[2 * kp + 1];
         if (s != 0.0 || s2 != 0.0) {
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(256) void small_eig_kernel(const double* __restrict
           A[q * EIG_LD + q2] = s2 * r21 + c2 * r22;
         }
       }
-      for (int i = tid; i < half * n; i += 256) {
+      for (int i = tid; i < half * n; i += EIG_THREADS) {
         const int k = i / n, j = i - k * n;
         const double c = cs[2 * k], s = cs[2 * k + 1];
         if (s != 0.0) {
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(256) void small_eig_kernel(const double* __restrict
   __syncthreads();
   double lmax = (n > 0) ? A[order[0] * EIG_LD + order[0]] : 0.0;
   double* no = Nout + (long)blockIdx.x * 4096;
-  for (int i = tid; i < 4096; i += 256) {
+  for (int i = tid; i < 4096; i += EIG_THREADS) {
     const int r = i >> 6, c = i & 63;
     double v = 0.0;
     if (r < n && c < n) {
@@ -252,7 +253,7 @@ int pmd_launch_small_eig(pmd_ctx* ctx, const double* G, int slices, int n, int m
   if (n > 64 || n < 1) return pmd_fail(ctx, PMD_ERR_UNSUPPORTED, "small_eig", "n must be in [1, 64]");
   const size_t bytes = (size_t)2 * 64 * EIG_LD * sizeof(double) + 64 * sizeof(double) + (64 + 2 + 64) * sizeof(int) + 64;
   PMD_HIP(ctx, hipFuncSetAttribute((const void*)small_eig_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-  hipLaunchKernelGGL(small_eig_kernel, dim3(n_tiles), dim3(256), bytes, ctx->stream, G, (long)slices * 4096, slices, n,
+  hipLaunchKernelGGL(small_eig_kernel, dim3(n_tiles), dim3(EIG_THREADS), bytes, ctx->stream, G, (long)slices * 4096, slices, n,
                      mode, tol, Nout, lam_out);
   PMD_LAUNCH_CHECK(ctx, "small_eig_kernel");
   return PMD_OK;
