@@ -184,6 +184,7 @@ def main():
         "roofline": roofline,
         "roofline_mfma": roofline_mfma,
         "phases_ms": {k: 1e3 * v for k, v in diag["timings"].items()},
+        "hbm_peak_allocated_gb": torch.cuda.max_memory_allocated(device) / 2 ** 30,
         "kernel_ms_per_step": {k: v[0] / args.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

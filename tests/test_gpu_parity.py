@@ -425,3 +425,25 @@ def test_full_pipeline_pixel_weighting_and_c_order(gpu_ctx):
     # Gram-eigh limit eps (sigma_1/sigma_c)^2 / gap ~ 8e-4 of BOTH implementations; all others are < 4e-5
     _check_full(pmd, diag, ref, mov, vt_tol_signal=6e-4)
     assert pmd.order == "C"
+
+
+@pytest.mark.parametrize("case", [
+    # (T, d1, d2, block, frame_range, kwargs)
+    dict(T=777, d1=33, d2=41, block=(12, 14), frames=500, kw=dict(max_components=7, background_rank=3, temporal_avg_factor=5)),
+    dict(T=1000, d1=48, d2=30, block=(16, 10), frames=1000, kw=dict(max_components=5, background_rank=1, spatial_avg_factor=1)),
+    dict(T=640, d1=64, d2=64, block=(32, 32), frames=640, kw=dict(max_components=12, background_rank=4, temporal_avg_factor=8)),
+    dict(T=450, d1=27, d2=52, block=(18, 26), frames=450, kw=dict(max_components=4, background_rank=0, max_consecutive_failures=2)),
+    dict(T=1210, d1=30, d2=30, block=(10, 10), frames=300, kw=dict(max_components=9, background_rank=2, compute_normalizer=False)),
+    dict(T=520, d1=44, d2=36, block=(22, 12), frames=520, kw=dict(max_components=6, background_rank=2, spatial_avg_factor=3,
+                                                              temporal_avg_factor=4)),
+])
+def test_full_pipeline_assorted_shapes(gpu_ctx, case):
+    """Ragged sizes: FOV not a multiple of the block stride (snapped last tiles), odd frame counts, every
+    averaging factor, no background, several allowed failures, no normaliser."""
+    mov = _movie(case["T"], case["d1"], case["d2"], seed=case["T"])
+    pmd, diag, ref = _compare_full(gpu_ctx, mov, case["block"], case["frames"], sim_iters=8, **case["kw"])
+    use_right = diag["rank_before"] > diag["crop"]
+    if use_right:
+        _check_full(pmd, diag, ref, mov, vt_tol=5e-3, orth_tol=1e-2, s_tol=3e-3, vt_tol_signal=2e-3)
+    else:
+        _check_full(pmd, diag, ref, mov, vt_tol=3e-3)
