@@ -35,7 +35,9 @@ namespace {
 
 constexpr int NB = 64;      // panel width
 constexpr int BR = 64;      // rows of one symv tile
-constexpr int CW = 1024;    // positions of one symv tile (4 waves x 64 lanes x float4)
+constexpr int CW = 1024;    // positions of one symv tile: 4 x 256 (2 row halves of 32 rows) or, for the
+                            // smaller trailing blocks, 512 = 2 x 256 (4 row quarters of 16 rows: half the registers,
+                            // two workgroups per CU, twice the workgroups)
 constexpr int DCH = 256;    // positions per dot-product workgroup
 
 struct sytrd_bufs {
@@ -48,10 +50,11 @@ struct sytrd_bufs {
   float* DP;    // [dot chunk][2][NB]: partial W_k^T v, V_k^T v
   double* NP;   // per advance workgroup: partial sum of squares
   float* scal;  // beta, tau, scale of the current reflector
+  int cw;       // tile width (positions) of the symv launch whose partials RP / CP / SP currently hold
 };
 
 __device__ __forceinline__ int tile_r0(int cs, int b) { return (cs + b * BR) & ~3; }
-__device__ __forceinline__ int tile_nq(int n, int cs, int b) { return (n - tile_r0(cs, b) + CW - 1) / CW; }
+__device__ __forceinline__ int tile_nq(int n, int cs, int b, int cw) { return (n - tile_r0(cs, b) + cw - 1) / cw; }
 
 // deterministic sum over the workgroup (nthreads <= 512); every thread gets the result
 template <typename T>
@@ -138,10 +141,10 @@ __global__ __launch_bounds__(320) void sytrd_advance_kernel(float* __restrict__ 
       const int cs = j;  // first row of the symv launch of column jp
       const int nbk = (n - cs + BR - 1) / BR;
       const int bc = (r - cs) / BR;
-      const int nq = tile_nq(n, cs, bc);
+      const int nq = tile_nq(n, cs, bc, B.cw);
       int bmax = bc;
       if (bc + 1 < nbk && tile_r0(cs, bc + 1) <= r) bmax = bc + 1;
-      ypart = batch_sum<3>(B.RP + r, B.ldp, part, 4, nq) + batch_sum<40>(B.CP + r, B.ldp, part, 4, bmax + 1);
+      ypart = batch_sum<10>(B.RP + r, B.ldp, part, 4, nq) + batch_sum<40>(B.CP + r, B.ldp, part, 4, bmax + 1);
       xv = A[(long)jp * ld + r];
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
@@ -228,16 +231,21 @@ __global__ __launch_bounds__(320) void sytrd_advance_kernel(float* __restrict__ 
 //       CP[b][r]  = sum_{c in tile, c <  r} A[c][r] v[c]
 //   dot workgroups: W_k^T v and V_k^T v over 256 positions for the k < j - j0 panel columns.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void sytrd_symv_kernel(const float* __restrict__ A, long ld, int n, int j, int j0,
+template <int CWT>
+__global__ __launch_bounds__(512, CWT == 1024 ? 2 : 4) void sytrd_symv_kernel(const float* __restrict__ A, long ld, int n, int j, int j0,
                                                          sytrd_bufs B, int n_np, int npairs, int nbk,
                                                          float* __restrict__ e, float* __restrict__ tau_out) {
+  constexpr int NPG = CWT / 256;   // position groups (256 positions = 64 lanes x float4 each)
+  constexpr int NRG = 8 / NPG;     // row groups
+  constexpr int RPW = BR / NRG;    // rows per wave: 32 or 16, all in flight at once
+  constexpr int LOGR = (RPW == 32) ? 5 : (RPW == 16) ? 4 : 3;
   __shared__ float s_v[BR];
-  __shared__ float s_row[4][BR];
-  __shared__ float s_col[4][64][4];
+  __shared__ float s_row[NPG][BR];
+  __shared__ float s_col[NPG][NRG - 1][64][4];
   __shared__ float s_red[8];
   __shared__ float s_sc[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wc = wave & 3, rh = wave >> 2;  // position group and row half of this wave
+  const int wc = wave % NPG, rh = wave / NPG;  // position group and row group of this wave
   const int cs = j + 1;
   const float* xr = A + (long)j * ld;
   const int wg = blockIdx.y * gridDim.x + blockIdx.x;
@@ -247,11 +255,11 @@ __global__ __launch_bounds__(512) void sytrd_symv_kernel(const float* __restrict
   int b = blockIdx.y, q = blockIdx.x;
   bool valid = !is_dot;
   if (valid) {
-    const int nq_b = tile_nq(n, cs, b);
+    const int nq_b = tile_nq(n, cs, b, CWT);
     if (q >= nq_b) {
       const int b2 = nbk - 1 - b;
       q -= nq_b;
-      if (b2 == b || q >= tile_nq(n, cs, b2)) valid = false;
+      if (b2 == b || q >= tile_nq(n, cs, b2, CWT)) valid = false;
       b = b2;
     }
   }
@@ -262,19 +270,19 @@ __global__ __launch_bounds__(512) void sytrd_symv_kernel(const float* __restrict
   const int cb = is_dot ? cs : cs + b * BR;
   const int rows = min(BR, n - cb);
   const int r0 = tile_r0(cs, is_dot ? 0 : b);
-  const int pos = r0 + (is_dot ? 0 : q) * CW + wc * 256 + lane * 4;
+  const int pos = r0 + (is_dot ? 0 : q) * CWT + wc * 256 + lane * 4;
   const int n4 = (n + 3) & ~3;
   const bool ok = pos < n4;
   // Every load of the tile is issued before anything waits: one memory round trip per workgroup.  The
   // loads are unconditional (clamped row / position, results masked later): a guarded load becomes a
   // branch with a full wait behind it.  Rows >= rows repeat the last row and meet v = 0.
-  float4 a[32];
+  float4 a[RPW];
   float v4[4];
   {
     const int posc = ok ? pos : r0;
     const float* ap = A + (long)cb * ld + posc;
 #pragma unroll
-    for (int uu = 0; uu < 32; ++uu) a[uu] = *reinterpret_cast<const float4*>(ap + (long)min(rh * 32 + uu, rows - 1) * ld);
+    for (int uu = 0; uu < RPW; ++uu) a[uu] = *reinterpret_cast<const float4*>(ap + (long)min(rh * RPW + uu, rows - 1) * ld);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int r = pos + t;
@@ -357,14 +365,14 @@ __global__ __launch_bounds__(512) void sytrd_symv_kernel(const float* __restrict
   if (tid < BR) s_v[tid] = (cb + tid == cs) ? 1.f : s_v[tid] * scale;
   __syncthreads();
 
-  const bool edge = (q == 0) || (r0 + (q + 1) * CW > n);
+  const bool edge = (q == 0) || (r0 + (q + 1) * CWT > n);
   float col[4] = {0.f, 0.f, 0.f, 0.f};
-  float pr[32];
+  float pr[RPW];
   if (edge) {
 #pragma unroll
-    for (int uu = 0; uu < 32; ++uu) {
-      const int c = cb + rh * 32 + uu;
-      const float vc = s_v[rh * 32 + uu];
+    for (int uu = 0; uu < RPW; ++uu) {
+      const int c = cb + rh * RPW + uu;
+      const float vc = s_v[rh * RPW + uu];
       // row part uses r >= c, column part r > c; nothing beyond n
       const float m0 = (pos + 0 < n) ? a[uu].x : 0.f, m1 = (pos + 1 < n) ? a[uu].y : 0.f,
                   m2 = (pos + 2 < n) ? a[uu].z : 0.f, m3 = (pos + 3 < n) ? a[uu].w : 0.f;
@@ -377,8 +385,8 @@ __global__ __launch_bounds__(512) void sytrd_symv_kernel(const float* __restrict
     }
   } else {
 #pragma unroll
-    for (int uu = 0; uu < 32; ++uu) {
-      const float vc = s_v[rh * 32 + uu];
+    for (int uu = 0; uu < RPW; ++uu) {
+      const float vc = s_v[rh * RPW + uu];
       pr[uu] = (a[uu].x * v4[0] + a[uu].y * v4[1]) + (a[uu].z * v4[2] + a[uu].w * v4[3]);
       col[0] += a[uu].x * vc;
       col[1] += a[uu].y * vc;
@@ -386,10 +394,11 @@ __global__ __launch_bounds__(512) void sytrd_symv_kernel(const float* __restrict
       col[3] += a[uu].w * vc;
     }
   }
-  // 32 row sums across the 64 lanes: halve the number of values per lane at every exchange
+  // RPW row sums across the 64 lanes: halve the number of values per lane at every exchange; after LOGR
+  // exchanges a lane holds one row (index = its top LOGR lane bits), the remaining lane bits are plain adds
 #pragma unroll
-  for (int s = 0; s < 5; ++s) {
-    const int off = 32 >> s, half = 16 >> s;
+  for (int s = 0; s < LOGR; ++s) {
+    const int off = 32 >> s, half = (RPW / 2) >> s;
     const bool upper = (lane & off) != 0;
 #pragma unroll
     for (int t = 0; t < half; ++t) {
@@ -398,22 +407,27 @@ __global__ __launch_bounds__(512) void sytrd_symv_kernel(const float* __restrict
       pr[t] = keep + __shfl_xor(send, off);
     }
   }
-  pr[0] += __shfl_xor(pr[0], 1);
-  if ((lane & 1) == 0) s_row[wc][rh * 32 + (lane >> 1)] = pr[0];
-  if (rh == 1) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) s_col[wc][lane][t] = col[t];
+  for (int off = 32 >> LOGR; off > 0; off >>= 1) pr[0] += __shfl_xor(pr[0], off);
+  if ((lane & ((64 >> LOGR) - 1)) == 0) s_row[wc][rh * RPW + (lane >> (6 - LOGR))] = pr[0];
+  if (rh > 0) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) s_col[wc][rh - 1][lane][t] = col[t];
   }
   __syncthreads();
   float spart = 0.f;
   if (tid < rows) {
-    const float rs = (s_row[0][tid] + s_row[1][tid]) + (s_row[2][tid] + s_row[3][tid]);
+    float rs = s_row[0][tid];
+#pragma unroll
+    for (int g = 1; g < NPG; ++g) rs += s_row[g][tid];
     B.RP[(long)q * B.ldp + cb + tid] = rs;
     spart = s_v[tid] * rs;
   }
   if (rh == 0) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) col[t] += s_col[wc][lane][t];
+    for (int g = 0; g < NRG - 1; ++g)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) col[t] += s_col[wc][g][lane][t];
     spart += (v4[0] * col[0] + v4[1] * col[1]) + (v4[2] * col[2] + v4[3] * col[3]);
     if (ok) *reinterpret_cast<float4*>(B.CP + (long)b * B.ldp + pos) = make_float4(col[0], col[1], col[2], col[3]);
   }
@@ -508,7 +522,7 @@ int pmd_apply_q_impl(pmd_ctx* ctx, int n, const float* A, long lda, const float*
 // ---------------------------------------------------------------------------------------------
 size_t pmd_sytrd_workspace_bytes_impl(int n) {
   const size_t n4 = (size_t)pmd_round_up(n, 4);
-  const size_t nq = (size_t)(n / CW + 2), nbk = (size_t)(n / BR + 2);
+  const size_t nq = (size_t)(n / 256 + 2), nbk = (size_t)(n / BR + 2);
   size_t b = 0;
   b += NB * n4 * sizeof(float) + 256;                 // W
   b += nq * n4 * sizeof(float) + 256;                 // RP
@@ -529,7 +543,7 @@ int pmd_sytrd_impl(pmd_ctx* ctx, int n, float* A, long lda, float* d, float* e, 
   if (lda % 4 != 0 || lda < n4 || ((uintptr_t)A & 15)) return pmd_fail(ctx, PMD_ERR_ARG, "pmd_sytrd", "lda must be a multiple of 4, >= round_up(n,4), A 16-byte aligned");
   pmd_arena ar(ws, ws_bytes);
   sytrd_bufs B;
-  const size_t nqmax = (size_t)(n / CW + 2), nbkmax = (size_t)(n / BR + 2);
+  const size_t nqmax = (size_t)(n / 256 + 2), nbkmax = (size_t)(n / BR + 2);
   B.ldw = n4;
   B.ldp = n4;
   B.W = ar.take_n<float>(NB * (size_t)n4);
@@ -541,6 +555,11 @@ int pmd_sytrd_impl(pmd_ctx* ctx, int n, float* A, long lda, float* d, float* e, 
   B.scal = ar.take_n<float>(16);
   if (ar.overflow) return pmd_fail(ctx, PMD_ERR_WORKSPACE, "pmd_sytrd", "workspace too small");
   hipStream_t st = ctx->stream;
+  const char* cwenv = getenv("PMD_SYMV_CW512_BELOW");
+  const int cw512_below = cwenv ? atoi(cwenv) : 1 << 30;
+  const char* cwf = getenv("PMD_SYMV_CW");
+  const int cw_fixed = cwf ? atoi(cwf) : 512;  // measured at n = 10^4: 334 ms (1024), 303 ms (512), 320 ms (256)
+  B.cw = CW;
   const float one = 1.f, minus1 = -1.f;
   int nsp = 0;
   for (int j0 = 0; j0 < n - 1; j0 += NB) {
@@ -556,7 +575,9 @@ int pmd_sytrd_impl(pmd_ctx* ctx, int n, float* A, long lda, float* d, float* e, 
       const int nbk = (n - cs + BR - 1) / BR;
       const int npairs = (nbk + 1) / 2;
       auto r0 = [&](int b) { return (cs + b * BR) & ~3; };
-      auto nq = [&](int b) { return (n - r0(b) + CW - 1) / CW; };
+      // narrower tiles (twice the workgroups, two per CU) below cw512_below trailing rows
+      const int cw = cw_fixed ? cw_fixed : ((n - cs < cw512_below) ? 512 : CW);
+      auto nq = [&](int b) { return (n - r0(b) + cw - 1) / cw; };
       int nqx = 1;
       for (int p = 0; p < npairs; ++p) nqx = std::max(nqx, nq(p) + ((nbk - 1 - p != p) ? nq(nbk - 1 - p) : 0));
       const int ndch = (i > 0) ? (n - cs + DCH - 1) / DCH : 0;
@@ -564,7 +585,13 @@ int pmd_sytrd_impl(pmd_ctx* ctx, int n, float* A, long lda, float* d, float* e, 
       {
         // with profiling on, every 64th column's product is timed on its own (bench.py: roofline of this kernel)
         pmd_prof_scope sample__((ctx->profile && (j & 63) == 32) ? ctx : nullptr, "sytrd_symv_sample");
-        hipLaunchKernelGGL(sytrd_symv_kernel, dim3(nqx, npairs + drows), dim3(512), 0, st, A, lda, n, j, j0, B, ga, npairs, nbk, e, tau);
+        if (cw == 256)
+          hipLaunchKernelGGL(sytrd_symv_kernel<256>, dim3(nqx, npairs + drows), dim3(512), 0, st, A, lda, n, j, j0, B, ga, npairs, nbk, e, tau);
+        else if (cw == 512)
+          hipLaunchKernelGGL(sytrd_symv_kernel<512>, dim3(nqx, npairs + drows), dim3(512), 0, st, A, lda, n, j, j0, B, ga, npairs, nbk, e, tau);
+        else
+          hipLaunchKernelGGL(sytrd_symv_kernel<1024>, dim3(nqx, npairs + drows), dim3(512), 0, st, A, lda, n, j, j0, B, ga, npairs, nbk, e, tau);
+        B.cw = cw;  // the advance launches that follow read these partials
       }
       nsp = nqx * npairs;
     }
