@@ -150,6 +150,15 @@ def main():
         "algorithmic_gb_per_launch": bytes_per_launch / 1e9,
         "hbm_gbs_equiv": bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
     }
+    # HBM-side traffic of the same launch from the committed PMC pass (profiles/r01_pmc_tile_atx.json: separate
+    # rocprofv3 --pmc FETCH_SIZE run, gfx950 x2 correction applied); only valid for the workload it was taken on
+    try:
+        pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_tile_atx.json")))
+        if args.config == DEFAULT_CONFIG:
+            roofline["traffic"] = pmc["fetch_bytes_per_launch"] / 1e9
+            roofline["traffic_unit"] = "GB per launch (L2 -> fabric reads, Infinity Cache hits included)"
+    except (OSError, KeyError, ValueError):
+        pass
     roofline_mfma = roofline
     # Dominant kernel by time: sytrd_symv (triangle matrix-vector product of the tridiagonalisation behind the
     # final SVD, one launch per column of the min(R', T)-sized Gram matrix).  Algorithmic bytes per launch =
