@@ -482,7 +482,7 @@ __global__ void tinv_kernel(float* __restrict__ S, int kb, const float* __restri
 // positions.  Blocks of QB reflectors in compact WY form, Q_blk = I - V T V^T with
 // T^{-1} = striu(V^T V) + diag(1/tau), applied last block first:  Z -= ((Z V) T^T) V^T.
 // Three GEMMs and one triangular solve per block (rocSOLVER's sormtr works in 64-column steps at ~20 TFLOP/s).
-constexpr int QB = 256;
+constexpr int QB = 1024;
 
 size_t pmd_apply_q_workspace_bytes_impl(int n) {
   return ((size_t)QB * n + (size_t)QB * QB + (size_t)n * QB) * sizeof(float) + 4096;
