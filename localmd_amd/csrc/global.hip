@@ -984,9 +984,11 @@ int pmd_gram_mtgm_impl(pmd_ctx* ctx, const float* M, int rows, int m, long ldm, 
   pmd_arena ar(ws, ws_bytes);
   float* Mt = ar.take_n<float>((size_t)m * rows);
   if (ar.overflow) return pmd_fail(ctx, PMD_ERR_WORKSPACE, "pmd_gram_mtgm", "workspace too small");
-  // row blocks C[i0:i0+bs, 0:i0+bs] = Mt[i0:i0+bs, :] GM[:, 0:i0+bs]  (9/16 of the flops at 8 blocks)
+  // row blocks C[i0:i0+bs, 0:i0+bs] = Mt[i0:i0+bs, :] GM[:, 0:i0+bs]  (3/5 of the flops at 5 blocks)
   RUN(launch_transpose(ctx, M, ldm, rows, m, Mt, rows));
-  const int bs = std::max(256, ((m + 7) / 8 + 255) / 256 * 256);
+  const char* cbenv = getenv("PMD_C_BLOCKS");
+  const int nblk = cbenv ? std::max(1, atoi(cbenv)) : 5;  // 2/3/4/5/6/8/12/16 blocks at m = 10^4: 70/64/57/52/59/58/60/67 ms
+  const int bs = std::max(256, ((m + nblk - 1) / nblk + 255) / 256 * 256);
   for (int i0 = 0; i0 < m; i0 += bs) {
     const int nr = std::min(bs, m - i0);
     RUN(pmd_gemm_rm(ctx, 0, 0, nr, i0 + nr, rows, 1.f, Mt + (long)i0 * rows, rows, GM, ldgm, 0.f, C + (long)i0 * ldc, ldc));
