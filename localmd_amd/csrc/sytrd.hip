@@ -441,6 +441,55 @@ __global__ __launch_bounds__(512, CWT == 1024 ? 2 : 4) void sytrd_symv_kernel(co
   }
 }
 
+// Panel update of the trailing block (slatrd's A22 -= V W^T + W V^T) on the triangle that is read:
+//   T[c][r] -= sum_k V_k[c] W_k[r] + W_k[c] V_k[r],   ts <= c <= r < n,  k < nbc <= 64.
+// One workgroup = one 64 x 64 tile (I <= J); wave w owns rows 16 w .. 16 w + 15 of it in four 16 x 16 fp32 MFMA
+// accumulators.  The operands are MFMA-fragment-shaped dword loads straight from the two 64-row panels (L2
+// resident, 16 consecutive floats per lane group); rocBLAS' ssyr2k spends several launches per call on this.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void sytrd_rank2k_kernel(float* __restrict__ A, long lda, int n, int ts, int j0, int nbc,
+                                                           const float* __restrict__ W, long ldw) {
+  const int I = blockIdx.y, J = blockIdx.x;
+  if (J < I) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n16 = lane & 15, kk = lane >> 4;
+  const int c0 = ts + 64 * I + 16 * wave, r0 = ts + 64 * J;
+  if (c0 >= n) return;
+  const float* V = A + (long)j0 * lda;
+  const int c = min(c0 + n16, n - 1);
+  int r[4];
+#pragma unroll
+  for (int jn = 0; jn < 4; ++jn) r[jn] = min(r0 + 16 * jn + n16, n - 1);
+  f32x4 acc[4];
+#pragma unroll
+  for (int jn = 0; jn < 4; ++jn) acc[jn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k0 = 0; k0 < 64; k0 += 4) {
+    const int k = k0 + kk;
+    const bool in = k < nbc;
+    const long kc = in ? k : 0;   // unconditional loads on a valid row, masked below
+    float a1 = V[kc * lda + c], a2 = W[kc * ldw + c];
+    a1 = in ? a1 : 0.f;
+    a2 = in ? a2 : 0.f;
+#pragma unroll
+    for (int jn = 0; jn < 4; ++jn) {
+      const float b1 = W[kc * ldw + r[jn]], b2 = V[kc * lda + r[jn]];
+      acc[jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[jn], 0, 0, 0);
+      acc[jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b2, acc[jn], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int jn = 0; jn < 4; ++jn) {
+    const int col = r0 + 16 * jn + n16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = c0 + 4 * kk + i;
+      if (row < n && col < n && col >= row) A[(long)row * lda + col] -= acc[jn][i];
+    }
+  }
+}
+
 __global__ void copy_rows_kernel(const float* __restrict__ src, long lds_, float* __restrict__ dst, long ldd, int n) {
   const int row = blockIdx.y;
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x)
@@ -557,6 +606,8 @@ int pmd_sytrd_impl(pmd_ctx* ctx, int n, float* A, long lda, float* d, float* e, 
   hipStream_t st = ctx->stream;
   const char* cwenv = getenv("PMD_SYMV_CW512_BELOW");
   const int cw512_below = cwenv ? atoi(cwenv) : 1 << 30;
+  const char* s2k = getenv("PMD_SYR2K");
+  const bool use_rocblas_syr2k = s2k && !strcmp(s2k, "rocblas");
   const char* cwf = getenv("PMD_SYMV_CW");
   const int cw_fixed = cwf ? atoi(cwf) : 512;  // measured at n = 10^4: 334 ms (1024), 303 ms (512), 320 ms (256)
   B.cw = CW;
@@ -599,9 +650,15 @@ int pmd_sytrd_impl(pmd_ctx* ctx, int n, float* A, long lda, float* d, float* e, 
     const int ts = j0 + nbc;
     hipLaunchKernelGGL((sytrd_advance_kernel<true, false>), dim3((n - ts + APOS - 1) / APOS), dim3(320), 0, st, A, lda, n, ts, j0, B, nsp, d);
     PMD_LAUNCH_CHECK(ctx, "sytrd_advance_kernel");
-    PMD_BLAS(ctx, rocblas_ssyr2k(ctx->blas, rocblas_fill_lower, rocblas_operation_none, n - ts, nbc, &minus1,
-                                 A + (long)j0 * lda + ts, (rocblas_int)lda, B.W + ts, (rocblas_int)B.ldw, &one,
-                                 A + (long)ts * lda + ts, (rocblas_int)lda));
+    if (use_rocblas_syr2k) {
+      PMD_BLAS(ctx, rocblas_ssyr2k(ctx->blas, rocblas_fill_lower, rocblas_operation_none, n - ts, nbc, &minus1,
+                                   A + (long)j0 * lda + ts, (rocblas_int)lda, B.W + ts, (rocblas_int)B.ldw, &one,
+                                   A + (long)ts * lda + ts, (rocblas_int)lda));
+    } else {
+      const int nt = (n - ts + 63) / 64;
+      hipLaunchKernelGGL(sytrd_rank2k_kernel, dim3(nt, nt), dim3(256), 0, st, A, lda, n, ts, j0, nbc, B.W, B.ldw);
+      PMD_LAUNCH_CHECK(ctx, "sytrd_rank2k_kernel");
+    }
   }
   hipLaunchKernelGGL((sytrd_advance_kernel<false, false>), dim3(1), dim3(320), 0, st, A, lda, n, n - 1, n - 1, B, 0, d);
   PMD_LAUNCH_CHECK(ctx, "sytrd_advance_kernel");
