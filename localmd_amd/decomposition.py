@@ -748,7 +748,10 @@ def localmd_decomposition(
         if use_right and rp <= T:
             nk = rp
             # device copy of R only where rows are exchanged between ranks; rank 0's own rows go straight to the host
-            R_out = torch.empty((Rc, nk), dtype=torch.float32, device=ctx.device) if shard else None
+            # Zero copy only for the large case it was measured on: for small outputs rocBLAS may pick split-K kernels
+            # that read-modify-write C, which is ruinous across PCIe (58 ms instead of 1 ms at 5015 x 1999).
+            zero_copy = (not shard or dist.rank == 0) and m_used >= 8192 and Rc * nk * 4 >= 2 ** 30
+            R_out = torch.empty((Rc, nk), dtype=torch.float32, device=ctx.device) if (shard or not zero_copy) else None
             s_out = torch.empty((nk,), dtype=torch.float32, device=ctx.device)
             Vt_out = torch.empty((nk, T), dtype=torch.float32, device=ctx.device)
             X1 = torch.empty((m_used, rp), dtype=torch.float32, device=ctx.device)
@@ -788,9 +791,11 @@ def localmd_decomposition(
             # against 75 ms into HBM plus 39 ms of download, scripts/gemm_probe3.hip).
             r_lo, r_hi = (row_lo, row_hi) if shard else (0, Rc)
             if r_hi > r_lo:
-                dst = r_host[r_lo:] if root else R_out[r_lo:]
+                dst = r_host[r_lo:] if (root and zero_copy) else R_out[r_lo:]
                 ctx.call("pmd_gemm", 0, 0, r_hi - r_lo, nk, m_used, 1.0, ptr(right[r_lo:]), m_cols, ptr(X1), rp, 0.0,
                          ptr(dst), nk)
+                if root and not zero_copy:
+                    download(r_lo, r_hi)
             if shard:
                 # the other ranks' row blocks of R travel to rank 0 and are downloaded as they arrive
                 ctx.sync()
