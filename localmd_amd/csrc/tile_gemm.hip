@@ -13,6 +13,7 @@
 // waves each own one 16-row MFMA tile.  All fp32 products run on v_mfma_f32_16x16x4_f32
 // (exact fp32 fmaf chains, 64 FLOP/clk/SIMD).
 #include "pmd_common.h"
+#include <cstdlib>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -198,6 +199,136 @@ __global__ __launch_bounds__(256 * KS * NS) void tile_atx_kernel(const float* __
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// tile_atx with LDS-DMA staging (KS = NS = 1, DPAD = 16 KJW <= 400): the X chunk (DPAD x 32 floats) goes from
+// global memory straight into LDS (global_load_lds_dwordx4: one wave instruction fills a contiguous 1 KiB =
+// 8 rows x 8 quads), no staging registers and no ds_write phase.  Three dense buffers form a ring, loads run two
+// chunks ahead, counted vmcnt + one raw barrier per chunk.  Rows are 32 floats with no padding; the quad index
+// is XORed with 4 * ((row >> 2) & 1) - applied on the global-address side by the loader and on the read side
+// by the MFMA operand fetch - so the four K slots of a lane group never share a bank.
+// Rows q >= dloc load the tile's first row (finite values meeting zero columns of A).
+// ------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* pmd_lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* pmd_gbl_ptr_t;
+
+template <int KJW>
+__global__ __launch_bounds__(256) void tile_atx_dma_kernel(const float* __restrict__ X, long ldx,
+                                                           const int* __restrict__ pix, int pix_stride,
+                                                           long row0_stride, int d, const float* __restrict__ A,
+                                                           long a_tile_stride, int a_ld, float* __restrict__ Out,
+                                                           long out_tile_stride, long ldo, int n_chunks_total,
+                                                           int chunks_per_slice) {
+  constexpr int DPAD = 16 * KJW;
+  constexpr int BUF = DPAD * 32;           // floats per ring buffer
+  constexpr int NINS = DPAD / 8;           // 1-KiB pieces per chunk
+  constexpr int NSLOT = (NINS + 3) / 4;    // pieces per wave
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tile = pmd_xcd_tile();
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int n16 = lane & 15, kk = lane >> 4;
+  const int dloc = min(d, DPAD);
+  const int c_begin = blockIdx.y * chunks_per_slice;
+  const int c_end = min(n_chunks_total, c_begin + chunks_per_slice);
+  if (c_begin >= c_end) return;
+
+  f32x4 areg[KJW];
+  {
+    const float* ap = A + (long)tile * a_tile_stride + (long)(16 * wid + n16) * a_ld + 4 * kk;
+#pragma unroll
+    for (int J = 0; J < KJW; ++J) areg[J] = *reinterpret_cast<const f32x4*>(ap + 16 * J);
+  }
+  // loader pieces: piece m covers rows 8m .. 8m+7; wave w issues m = w, w+4, ...
+  const float* gsrc[NSLOT];
+#pragma unroll
+  for (int k = 0; k < NSLOT; ++k) {
+    const int m = min(wid + 4 * k, NINS - 1);
+    const int q = 8 * m + (lane >> 3), p = lane & 7;
+    const int f = 4 * ((q >> 2) & 1);
+    const int qc = (q < dloc) ? q : 0;
+    const long row = pix ? (long)pix[(long)tile * pix_stride + qc] : (long)tile * row0_stride + qc;
+    gsrc[k] = X + row * ldx + 4 * (p ^ f);
+  }
+  auto issue = [&](int c, int buf) {
+#pragma unroll
+    for (int k = 0; k < NSLOT; ++k) {
+      if (wid + 4 * k < NINS)
+        __builtin_amdgcn_global_load_lds((pmd_gbl_ptr_t)(gsrc[k] + (long)c * 32),
+                                         (pmd_lds_ptr_t)(lds + buf * BUF + 8 * (wid + 4 * k) * 32), 16, 0, 0);
+    }
+  };
+  // loads past the slice end read the next chunks of the same rows (rows carry PMD_LD_SLACK = 64 spare floats)
+  issue(c_begin, 0);
+  issue(c_begin + 1, 1);
+  constexpr int MYINS = NSLOT;  // upper bound of this wave's pieces per chunk (the last slot may be void)
+  // wait for chunk c_begin: at most the pieces of chunk c_begin + 1 may still be in flight
+  if (wid + 4 * (NSLOT - 1) < NINS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MYINS) : "memory");
+  else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MYINS - 1) : "memory");
+  __builtin_amdgcn_s_barrier();
+  const int f = 4 * (kk & 1);
+  const int off0 = (4 * kk) * 32 + (((n16 >> 2) ^ f) << 2) + (n16 & 3);
+  const int off1 = (4 * kk) * 32 + (((4 + (n16 >> 2)) ^ f) << 2) + (n16 & 3);
+  float* outp = Out + (long)tile * out_tile_stride + (long)(16 * wid + 4 * kk) * ldo + n16;
+  const bool full = wid + 4 * (NSLOT - 1) < NINS;  // this wave issues NSLOT (else NSLOT - 1) pieces per chunk
+  for (int c = c_begin; c < c_end; ++c) {
+    const int cur = (c - c_begin) % 3;
+    issue(c + 2, (c - c_begin + 2) % 3);
+    const float* x0 = lds + cur * BUF + off0;
+    const float* x1 = lds + cur * BUF + off1;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    float b0[4], b1[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { b0[s] = x0[s * 32]; b1[s] = x1[s * 32]; }
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+#pragma unroll
+    for (int J = 0; J < KJW; ++J) {
+      float n0[4], n1[4];
+      if (J + 1 < KJW) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { n0[s] = x0[(16 * (J + 1) + s) * 32]; n1[s] = x1[(16 * (J + 1) + s) * 32]; }
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[J][s], b0[s], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[J][s], b1[s], acc1, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+      if (J + 1 < KJW) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { b0[s] = n0[s]; b1[s] = n1[s]; }
+      }
+    }
+    {
+      float* o = outp + (long)c * 32;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { o[(long)i * ldo] = acc0[i]; o[(long)i * ldo + 16] = acc1[i]; }
+    }
+    // chunk c + 1 must have landed: still allowed in flight are the pieces of chunk c + 2 and the 8 stores above
+    if (full) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MYINS + 8) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MYINS - 1 + 8) : "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no DMA write may outlive the workgroup's LDS allocation
+}
+
+template <int KJW>
+static int launch_atx_dma(pmd_ctx* ctx, const float* X, long ldx, const int* pix, int pix_stride, long row0_stride, int d,
+                          const float* A, long a_tile_stride, int a_ld, float* Out, long out_tile_stride, long ldo,
+                          int n_tiles, int T, int slices) {
+  const size_t lds = (size_t)3 * 16 * KJW * 32 * sizeof(float);
+  auto kern = tile_atx_dma_kernel<KJW>;
+  PMD_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int n_chunks = (T + 31) / 32;
+  if (slices < 1) slices = 1;
+  if (slices > n_chunks) slices = n_chunks;
+  const int cps = (n_chunks + slices - 1) / slices;
+  const int ny = (n_chunks + cps - 1) / cps;
+  hipLaunchKernelGGL(kern, dim3(n_tiles, ny, 1), dim3(256), lds, ctx->stream, X, ldx, pix, pix_stride, row0_stride, d, A,
+                     a_tile_stride, a_ld, Out, out_tile_stride, ldo, n_chunks, cps);
+  PMD_LAUNCH_CHECK(ctx, "tile_atx_dma_kernel");
+  return PMD_OK;
+}
+
 template <int KJW, int KS, int NS>
 static int launch_atx_variant(pmd_ctx* ctx, const float* X, long ldx, const int* pix, int pix_stride, long row0_stride,
                               int d, const float* A, long a_tile_stride, int a_ld, float* Out, long out_tile_stride,
@@ -240,6 +371,14 @@ int pmd_launch_tile_atx(pmd_ctx* ctx, const float* X, long ldx, const int* pix, 
   if (v.kjw == KJW_ && v.ks == KS_)                                                                                      \
     return launch_atx_variant<KJW_, KS_, NS_>(ctx, X, ldx, pix, pix_stride, row0_stride, d, A, a_tile_stride, a_ld, Out, \
                                               out_tile_stride, ldo, n_tiles, T, slices, kz);
+  // d in (256, 400]: LDS-DMA staged variant (needs the two spare chunks behind every row: ldx >= 32 (chunks + 2))
+  {
+    const char* dm = getenv("PMD_ATX_DMA");
+    const bool dma_ok = !(dm && !strcmp(dm, "0")) && ldx >= 32L * ((T + 31) / 32 + 2) && (ldx % 4) == 0;
+    if (v.kjw == 25 && v.ks == 1 && dma_ok)
+      return launch_atx_dma<25>(ctx, X, ldx, pix, pix_stride, row0_stride, d, A, a_tile_stride, a_ld, Out, out_tile_stride,
+                                ldo, n_tiles, T, slices);
+  }
   ATX_CASE(16, 1, 2)
   ATX_CASE(25, 1, 1)
   ATX_CASE(32, 1, 1)
