@@ -23,6 +23,10 @@ CONFIGS = {
     "demo_60x80x2000": dict(T=2000, d1=60, d2=80, block=20, frames=100, max_components=50),
     "256x256x2000_b20_r8": dict(T=2000, d1=256, d2=256, block=20, frames=2000, max_components=8),
     "512x512x10000_b20": dict(T=10000, d1=512, d2=512, block=20, frames=10000, max_components=50),
+    # spatial size / block of BASELINE config 4 with a time axis that fits one GPU next to its working copies
+    "1024x1024x2000_b32": dict(T=2000, d1=1024, d2=1024, block=32, frames=2000, max_components=50),
+    # block / overlap of BASELINE config 5 on a quarter of its field of view
+    "1024x1024x1000_b16": dict(T=1000, d1=1024, d2=1024, block=16, frames=1000, max_components=50),
 }
 DEFAULT_CONFIG = "512x512x10000_b20"
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, dense f32 matrix peak

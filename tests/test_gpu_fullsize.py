@@ -107,3 +107,34 @@ def test_config3_512x512x10000_properties(gpu_ctx):
     assert len(diag["tile_ranks"]) == 2601
     _check_properties(pmd, diag, noisy, T, d1, d2, block)
     gpu_ctx.release_workspace()
+
+
+def test_many_small_tiles_1024x1024_b16(gpu_ctx):
+    """Block 16x16 with 50 % overlap on a 1024x1024 field of view (the tile shape of BASELINE config 5 on a
+    quarter of its FOV): 16129 tiles, R ~ 3e5 >> frames."""
+    import torch
+
+    free, total = torch.cuda.mem_get_info()
+    if total < 100 * 2 ** 30:
+        pytest.skip("needs an MI355X-class HBM capacity")
+    T, d1, d2, block = 600, 1024, 1024, 16
+    pmd, diag, noisy = _decompose(gpu_ctx, T, d1, d2, block, 50)
+    assert len(diag["tile_ranks"]) == 127 * 127
+    assert diag["rank_before"] > diag["crop"] and diag["orthogonalizer"] == "cholesky"
+    _check_properties(pmd, diag, noisy, T, d1, d2, block)
+    gpu_ctx.release_workspace()
+
+
+def test_large_tiles_1024x1024_b32(gpu_ctx):
+    """Block 32x32 (1024-pixel tiles, the K-split tile kernels) on a 1024x1024 field of view: the spatial
+    shape of BASELINE config 4 with a short time axis."""
+    import torch
+
+    free, total = torch.cuda.mem_get_info()
+    if total < 100 * 2 ** 30:
+        pytest.skip("needs an MI355X-class HBM capacity")
+    T, d1, d2, block = 800, 1024, 1024, 32
+    pmd, diag, noisy = _decompose(gpu_ctx, T, d1, d2, block, 50)
+    assert len(diag["tile_ranks"]) == 63 * 63
+    _check_properties(pmd, diag, noisy, T, d1, d2, block)
+    gpu_ctx.release_workspace()
