@@ -545,6 +545,69 @@ __global__ __launch_bounds__(256) void tile_gram_kernel(const float* __restrict_
     for (int b = 0; b < 4; ++b) g[(4 * ti + a) * 64 + 4 * tj + b] = acc[a][b];
 }
 
+// fp64-MFMA form (v_mfma_f64_16x16x4_f64: A[m = l%16][k = l/16], B[k = l/16][n = l%16], D[4i + l/16][l%16]).
+// Wave w owns the 16-row tile w of the 64 x 64 result (four 16 x 16 accumulators).  Per macro step of 16
+// positions a lane loads one float4 per row tile (row 16t + l%16, positions 4(l/16) .. +3); element s of those
+// float4 feeds MFMA s, i.e. the K slots walk the positions in a permuted order - harmless for a sum over all of
+// them as long as both operands use the same permutation, which they do (they are the same registers).
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void tile_gram_mfma_kernel(const float* __restrict__ In, long tile_stride, long ld,
+                                                             int len, int chunk_per_slice, double* __restrict__ G,
+                                                             long g_tile_stride) {
+  const int tile = blockIdx.x, slice = blockIdx.y;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int m16 = lane & 15, kq = lane >> 4;
+  const float* in = In + (long)tile * tile_stride + (long)m16 * ld + 4 * kq;
+  const int x_begin = slice * chunk_per_slice;
+  const int x_end = min(len, x_begin + chunk_per_slice);
+  f64x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = (f64x4){0.0, 0.0, 0.0, 0.0};
+  // one step = 32 positions = two quads per lane and row tile; the next step's eight loads are in flight
+  // while the 32 MFMAs of the current one run
+  auto load = [&](int x0, f32x4 (&v)[8]) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      // unconditional loads (rows always exist; positions are clamped to the row's last aligned quad), masked below
+      const int xh = x0 + 16 * h;
+      const int xq = min(xh, ((int)ld - 4) - 4 * kq);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) v[4 * h + t] = *reinterpret_cast<const f32x4*>(in + (long)(16 * t) * ld + xq);
+      const int xs = xh + 4 * kq;
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (xs + e >= x_end || xq != xh) v[4 * h + t][e] = 0.f;
+    }
+  };
+  f32x4 cur[8], nxt[8];
+  if (x_begin < x_end) load(x_begin, cur);
+  for (int x0 = x_begin; x0 < x_end; x0 += 32) {
+    const bool more = x0 + 32 < x_end;
+    if (more) load(x0 + 32, nxt);
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const double a = (double)(w == 0 ? cur[4 * h][e] : w == 1 ? cur[4 * h + 1][e] : w == 2 ? cur[4 * h + 2][e] : cur[4 * h + 3][e]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, (double)cur[4 * h + t][e], acc[t], 0, 0, 0);
+      }
+    if (more) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) cur[t] = nxt[t];
+    }
+  }
+  double* g = G + (long)tile * g_tile_stride + (long)slice * 4096;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) g[(16 * w + 4 * i + kq) * 64 + 16 * t + m16] = acc[t][i];
+}
+
 // G: [tile][slices][64][64] doubles, g_tile_stride = slices*4096.
 int pmd_launch_tile_gram(pmd_ctx* ctx, const float* In, long tile_stride, long ld, int len, int n_tiles, int slices,
                          double* G) {
@@ -553,8 +616,13 @@ int pmd_launch_tile_gram(pmd_ctx* ctx, const float* In, long tile_stride, long l
   if (slices < 1) slices = 1;
   int cps = (len + slices - 1) / slices;
   cps = (int)pmd_round_up(cps, 32);
-  hipLaunchKernelGGL(tile_gram_kernel, dim3(n_tiles, slices), dim3(256), 0, ctx->stream, In, tile_stride, ld, len, cps,
-                     G, (long)slices * 4096);
+  const char* gm = getenv("PMD_GRAM_MFMA");
+  if (!(gm && !strcmp(gm, "0")) && ld % 4 == 0 && ld >= 16 && tile_stride % 4 == 0 && !((uintptr_t)In & 15))
+    hipLaunchKernelGGL(tile_gram_mfma_kernel, dim3(n_tiles, slices), dim3(256), 0, ctx->stream, In, tile_stride, ld, len,
+                       cps, G, (long)slices * 4096);
+  else
+    hipLaunchKernelGGL(tile_gram_kernel, dim3(n_tiles, slices), dim3(256), 0, ctx->stream, In, tile_stride, ld, len, cps,
+                       G, (long)slices * 4096);
   PMD_LAUNCH_CHECK(ctx, "tile_gram_kernel");
   return PMD_OK;
 }
