@@ -698,6 +698,63 @@ __global__ __launch_bounds__(256) void tile_rowmix_kernel(const float* __restric
   }
 }
 
+// fp64-MFMA form for n_out > 4.  Wave w owns output rows 16 w .. 16 w + 15: its slice of N^T (A operand,
+// A[m][k] = N[k][16 w + m]) stays in registers (16 doubles per lane) for the whole sweep; per chunk of 16
+// positions a lane loads In[4 ks + l/16][x0 + l%16] for the 16 K steps (B operand) and issues 16 MFMAs.
+// In-place safe: all four waves have consumed the chunk's inputs (barrier) before anyone stores its outputs;
+// the next chunk (other positions) is prefetched before that barrier.
+__global__ __launch_bounds__(256) void tile_rowmix_mfma_kernel(const float* __restrict__ In, long in_tile_stride,
+                                                               long ld_in, const double* __restrict__ N,
+                                                               long n_tile_stride, int n_in, int n_out,
+                                                               float* __restrict__ Out, long out_tile_stride,
+                                                               long ld_out, int len) {
+  const int tile = blockIdx.y;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int n16 = lane & 15, kq = lane >> 4;
+  const double* nsrc = N + (long)tile * n_tile_stride;
+  double a[16];
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) {
+    const int cp = 4 * ks + kq, c = 16 * w + n16;
+    const double v = nsrc[cp * 64 + c];   // the 64 x 64 block always exists; entries outside n_in x n_out are masked
+    a[ks] = (cp < n_in && c < n_out) ? v : 0.0;
+  }
+  const float* in = In + (long)tile * in_tile_stride;
+  float* out = Out + (long)tile * out_tile_stride;
+  const int ksteps = (n_in + 3) / 4;
+  auto load = [&](int x0, float (&v)[16]) {
+    const int x = min(x0 + n16, len - 1);
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const float t = in[(long)min(4 * ks + kq, 63) * ld_in + x];   // unconditional, rows < 64 exist
+      v[ks] = (4 * ks + kq < n_in) ? t : 0.f;                       // rows >= n_in may hold anything: 0 * NaN
+    }
+  };
+  float cur[16], nxt[16];
+  int x0 = blockIdx.x * 16;
+  if (x0 < len) load(x0, cur);
+  for (; x0 < len; x0 += gridDim.x * 16) {
+    const int xn = x0 + gridDim.x * 16;
+    if (xn < len) load(xn, nxt);
+    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+      if (ks < ksteps) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], (double)cur[ks], acc, 0, 0, 0);
+    __syncthreads();   // every wave holds this chunk's inputs in registers: outputs may overwrite them now
+    if (x0 + n16 < len) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = 16 * w + 4 * i + kq;
+        out[(long)c * ld_out + x0 + n16] = (c < n_out) ? (float)acc[i] : 0.f;
+      }
+    }
+    if (xn < len) {
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) cur[ks] = nxt[ks];
+    }
+  }
+}
+
 int pmd_launch_tile_rowmix(pmd_ctx* ctx, const float* In, long in_tile_stride, long ld_in, const double* N,
                            long n_tile_stride, int n_in, int n_out, float* Out, long out_tile_stride, long ld_out,
                            int len, int n_tiles) {
@@ -710,7 +767,13 @@ int pmd_launch_tile_rowmix(pmd_ctx* ctx, const float* In, long in_tile_stride, l
     const float* in = In + (long)t0 * in_tile_stride;
     const double* nn = N + (long)t0 * n_tile_stride;
     float* out = Out + (long)t0 * out_tile_stride;
-    if (n_out <= 4)
+    const char* rm = getenv("PMD_ROWMIX_MFMA");
+    if (n_out > 4 && !(rm && !strcmp(rm, "0"))) {
+      int bxm = (len + 15) / 16;
+      if (bxm > 16) bxm = 16;
+      hipLaunchKernelGGL(tile_rowmix_mfma_kernel, dim3(bxm, tn), dim3(256), 0, ctx->stream, in, in_tile_stride, ld_in, nn,
+                         n_tile_stride, n_in, n_out, out, out_tile_stride, ld_out, len);
+    } else if (n_out <= 4)
       hipLaunchKernelGGL(tile_rowmix_kernel<4>, dim3(bx, tn), dim3(256), 0, ctx->stream, in, in_tile_stride, ld_in, nn,
                          n_tile_stride, n_in, n_out, out, out_tile_stride, ld_out, len);
     else if (n_out <= 32)
