@@ -191,9 +191,9 @@ def main():
                    "rank_before": diag["rank_before"], "rank_after": diag["rank_after"],
                    "mean_tile_rank": float(np.mean(diag["tile_ranks"])),
                    "parallelism": "1 process per GPU" + (
-                       f", tile grid and the rows of the global stage sharded over {world} ranks (tile results gathered, "
-                       "the two frames x frames Gram matrices all-reduced, R collected on rank 0; statistics and the "
-                       "m x m Cholesky / eigen stage replicated)" if world > 1 else "")},
+                       f", bands of tile rows / pixel slabs and the rows of the global stage sharded over {world} ranks "
+                       "(tile results gathered, background projection and the two frames x frames Gram matrices "
+                       "all-reduced, R collected on rank 0; the m x m Cholesky / eigen stage replicated)" if world > 1 else "")},
         "roofline": roofline,
         "roofline_mfma": roofline_mfma,
         "phases_ms": {k: 1e3 * v for k, v in diag["timings"].items()},

@@ -13,8 +13,12 @@ two roughness cut-offs instead of simulating them), ``sim_iters``, ``return_diag
 "eigh" is the reference's eigendecomposition (decomposition.py:984-996); "cholesky" uses the
 Cholesky factor of the same Gram matrix (P differs by an orthogonal factor that the final SVD
 absorbs, so R, s, Vt are the same); "auto" (default) = cholesky with eigh as fallback.
-``distributed=True`` (one process per GPU, torch.distributed initialised): the tile grid is split
-over the ranks, per-tile results are gathered, every rank returns the same PMDArray.
+``distributed=True`` (one process per GPU, torch.distributed initialised): every rank owns a band of tile
+rows and keeps only the pixel slab those tiles touch (statistics, standardisation, tile fits and the movie
+projection run on the slab); sums over pixels (background projection) and over component rows (the two
+Gram matrices of the Cholesky route) are all-reduced, per-tile results are gathered, R is collected on rank 0.
+Rank 0 returns the PMDArray; on the row-sharded route the other ranks return None.  Random draws (seed,
+frame sample, frame windows) are rank 0's.
 """
 import datetime
 import math
@@ -80,23 +84,27 @@ def _dbg(name, t):
 class _Movie:
     """The (T, D) float32 movie resident in HBM, plus the pixel-major standardised copies."""
 
-    def __init__(self, ctx, dataset_obj, frame_batch_size):
+    def __init__(self, ctx, dataset_obj, frame_batch_size, rows=None):
+        """rows = (i_lo, i_hi): keep only these FOV rows (first spatial axis) - the pixel slab of one rank.
+        self.D is the number of resident pixels; pixel c of the slab is FOV pixel c + i_lo * d2 (C order)."""
         torch = _torch()
         self.ctx = ctx
         shape = tuple(int(x) for x in dataset_obj.shape)
         self.T, self.d1, self.d2 = shape
-        self.D = self.d1 * self.d2
+        i_lo, i_hi = (0, self.d1) if rows is None else rows
+        self.D = (i_hi - i_lo) * self.d2
         if isinstance(dataset_obj, torch.Tensor):
-            mv = dataset_obj.to(device=ctx.device, dtype=torch.float32)
+            mv = dataset_obj[:, i_lo:i_hi, :].to(device=ctx.device, dtype=torch.float32)
             self.dev = mv.reshape(self.T, self.D).contiguous()
         else:
             self.dev = torch.empty((self.T, self.D), dtype=torch.float32, device=ctx.device)
             step = max(1, int(frame_batch_size))
             for t0 in range(0, self.T, step):
                 keys = list(range(t0, min(self.T, t0 + step)))
-                chunk = np.asarray(dataset_obj[keys], dtype=np.float32).reshape(len(keys), self.D)
+                chunk = np.asarray(dataset_obj[keys], dtype=np.float32)[:, i_lo:i_hi, :].reshape(len(keys), self.D)
                 self.dev[t0 : t0 + len(keys)].copy_(torch.from_numpy(np.ascontiguousarray(chunk)))
-        self.rows_alloc = _round_up(self.D, 1024)
+        # one extra block of zero rows: kernels that walk the rows in 1024-blocks may start at any owned offset
+        self.rows_alloc = _round_up(self.D, 1024) + 1024
 
     def standardized(self, frames, mean, std):
         """Pixel-major (rows_alloc x ld) standardised frames; frames=None means all, in order."""
@@ -303,9 +311,31 @@ def localmd_decomposition(
         seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         D = d1 * d2
 
+        # ---- multi-GPU ownership (distributed=True): rank r decomposes a band of tile rows and keeps only the
+        # FOV rows those tiles touch (its pixel slab, P_lo <= c < P_hi in C-order pixel ids); every pixel is OWNED
+        # by exactly one rank (O_lo <= c < O_hi, the slab minus the halo shared with the next rank) for the sums
+        # over pixels.  Single process: slab = owned range = the whole field of view.
+        dist = Dist(distributed)
+        seed = dist.broadcast_object(seed)   # drawn from np.random when not given: rank 0's draw counts
+        geo_blocks = grid.update_block_sizes(list(block_sizes), (d1, d2), display=None)
+        geo_o1, geo_o2 = grid.tile_origins((d1, d2), geo_blocks)
+        n1_geo, n2_geo = len(geo_o1), len(geo_o2)
+        if dist.enabled and dist.world > n1_geo:
+            raise ValueError("distributed=True needs at least one tile row per rank ({} rows, {} ranks)".format(n1_geo, dist.world))
+        row_runs = tile_partition(n1_geo, dist.world)
+        runs = [(a * n2_geo, b * n2_geo) for a, b in row_runs]
+        a_lo, a_hi = row_runs[dist.rank]
+        i_lo, i_hi = (int(geo_o1[a_lo]), int(geo_o1[a_hi - 1]) + int(geo_blocks[0])) if dist.enabled else (0, d1)
+        own_starts = [int(geo_o1[a]) for a, _ in row_runs] + [d1]
+        own_starts[0] = 0
+        owned = [(own_starts[k] * d2, own_starts[k + 1] * d2) for k in range(dist.world)]
+        P_lo, P_hi = i_lo * d2, i_hi * d2
+        O_lo, O_hi = owned[dist.rank] if dist.enabled else (0, D)
+
         # ---- PMDLoader.__init__ (pmd_loader.py:112-173): movie to HBM, statistics, background basis
         t0 = time.perf_counter()
-        movie = _Movie(ctx, dataset_obj, frame_batch_size)
+        movie = _Movie(ctx, dataset_obj, frame_batch_size, rows=(i_lo, i_hi) if dist.enabled else None)
+        Dl = movie.D   # resident pixels (= D unless distributed)
         lap("upload", t0)
         display("Computing Video Statistics")
         if compute_normalizer:
@@ -314,10 +344,10 @@ def localmd_decomposition(
             display("We are not normalizing each pixel by a noise variance estimate")
         display("Calculating mean and noise variance")
         t0 = time.perf_counter()
-        mean_dev = torch.empty(D, dtype=torch.float32, device=ctx.device)
-        std_dev = torch.empty(D, dtype=torch.float32, device=ctx.device)
-        ws = ctx.workspace(lib.pmd_stats_workspace_bytes(T, D, 1024))
-        ctx.call("pmd_stats", ptr(movie.dev), T, D, 1024, 1 if compute_normalizer else 0, ptr(mean_dev), ptr(std_dev),
+        mean_dev = torch.empty(Dl, dtype=torch.float32, device=ctx.device)
+        std_dev = torch.empty(Dl, dtype=torch.float32, device=ctx.device)
+        ws = ctx.workspace(lib.pmd_stats_workspace_bytes(T, Dl, 1024))
+        ctx.call("pmd_stats", ptr(movie.dev), T, Dl, 1024, 1 if compute_normalizer else 0, ptr(mean_dev), ptr(std_dev),
                  ptr(ws), ws.numel())
         display("Finished mean and noise variance")
         lap("stats", t0)
@@ -326,8 +356,15 @@ def localmd_decomposition(
         K = int(background_rank)
         basis_dev = None
         if K > 0:
-            sample = np.random.choice(list(range(T)), replace=False, size=min(1000, T)).tolist()
+            sample = dist.broadcast_object(np.random.choice(list(range(T)), replace=False, size=min(1000, T)).tolist())
             xs_s, ld_s = movie.standardized(sample, mean_dev, std_dev)
+            if dist.enabled:
+                # the (<= 1000 frame) sample is small: every rank contributes its owned pixels, all get the whole
+                # sample and compute the same basis (same counter-based test matrix)
+                xs_all = torch.zeros((_round_up(D, 1024) + 1024, ld_s), dtype=torch.float32, device=ctx.device)
+                xs_all[O_lo:O_hi] = xs_s[O_lo - P_lo:O_hi - P_lo]
+                dist.gather_runs(xs_all, owned)
+                xs_s = xs_all
             basis_dev = torch.empty((D, K), dtype=torch.float32, device=ctx.device)
             ws = ctx.workspace(lib.pmd_background_rsvd_workspace_bytes(D, len(sample)))
             ctx.call("pmd_background_rsvd", ptr(xs_s), D, len(sample), ld_s, K, seed, ptr(basis_dev), ptr(ws), ws.numel())
@@ -346,7 +383,7 @@ def localmd_decomposition(
         else:
             if frame_range <= window_chunks:
                 window_chunks = frame_range
-            frames = grid.identify_window_chunks(frame_range, T, window_chunks, display=display)
+            frames = dist.broadcast_object(grid.identify_window_chunks(frame_range, T, window_chunks, display=display))
         display("We are initializing on a total of {} frames".format(len(frames)))
         Tf = len(frames)
 
@@ -383,17 +420,20 @@ def localmd_decomposition(
         pj_dev = None
         if K > 0:
             pj_dev = torch.zeros((K, ld_f), dtype=torch.float32, device=ctx.device)
-            ws = ctx.workspace(lib.pmd_bg_project_workspace_bytes(D, Tf))
-            ctx.call("pmd_bg_project", ptr(xs_init), D, Tf, ld_f, ptr(basis_dev), K, ptr(pj_dev), ld_f, ptr(ws), ws.numel())
-            xf = torch.empty_like(xs_init)   # bg_filter writes all ld columns of the D pixel rows
-            if xf.shape[0] > D:
-                xf[D:].zero_()
-            ctx.call("pmd_bg_filter", ptr(xs_init), ptr(xf), D, Tf, ld_f, ptr(basis_dev), K, ptr(pj_dev), ld_f)
+            # projection on the background basis: a sum over pixels - owned pixels here, summed over the ranks
+            ws = ctx.workspace(lib.pmd_bg_project_workspace_bytes(O_hi - O_lo, Tf))
+            ctx.call("pmd_bg_project", ptr(xs_init[O_lo - P_lo:]), O_hi - O_lo, Tf, ld_f, ptr(basis_dev[O_lo:]), K, ptr(pj_dev),
+                     ld_f, ptr(ws), ws.numel())
+            dist.all_reduce(pj_dev)
+            xf = torch.empty_like(xs_init)   # bg_filter writes all ld columns of the resident pixel rows
+            if xf.shape[0] > Dl:
+                xf[Dl:].zero_()
+            ctx.call("pmd_bg_filter", ptr(xs_init), ptr(xf), Dl, Tf, ld_f, ptr(basis_dev[P_lo:]), K, ptr(pj_dev), ld_f)
         else:
             xf = xs_init.clone() if pixel_weighting is not None else xs_init
         if pixel_weighting is not None:
-            pw = _f32(ctx, np.asarray(pixel_weighting, dtype=np.float32).reshape(-1))
-            ctx.call("pmd_scale_rows", ptr(xf), D, Tf, ld_f, ptr(pw))
+            pw = _f32(ctx, np.asarray(pixel_weighting, dtype=np.float32).reshape(-1)[P_lo:P_hi])
+            ctx.call("pmd_scale_rows", ptr(xf), Dl, Tf, ld_f, ptr(pw))
         lap("standardize_filter", t0)
 
         # ---- tile grid (decomposition.py:721-773)
@@ -437,15 +477,18 @@ def localmd_decomposition(
         keep_dev = torch.zeros((n_tiles, 64), dtype=torch.int32, device=ctx.device)
         ranks_dev = torch.zeros((n_tiles,), dtype=torch.int32, device=ctx.device)
         lam_dev = torch.zeros((n_tiles, 64), dtype=torch.float64, device=ctx.device)
-        dist = Dist(distributed)
-        runs = tile_partition(n_tiles, dist.world)
-        t_lo, t_hi = runs[dist.rank]
+        assert n_tiles == n1_geo * n2_geo
+        t_lo, t_hi = runs[dist.rank] if dist.enabled else (0, n_tiles)
+        if not dist.enabled:
+            runs = [(0, n_tiles)]
         n_loc = t_hi - t_lo
+        # pixel lists of this rank's tiles relative to its slab (the kernels that read the movie copies)
+        pix_loc_dev = _i32(ctx, pix_c[t_lo:t_hi] - P_lo) if dist.enabled else pix_dev
         thr_s32, thr_t32 = float(np.float32(spatial_threshold)), float(np.float32(temporal_threshold))
         a_f = int(temporal_avg_factor)
         if n_loc > 0 and n_win == 1:
-            ws = ctx.workspace(lib.pmd_tiles_workspace_bytes(n_loc, b1, b2, P_pool, r, a_f, crop, ldv, D))
-            ctx.call("pmd_tiles_decompose", ptr(xf), ld_f, D, crop, ptr(pix_dev[t_lo:]), n_loc, b1, b2, ptr(pool_q_dev),
+            ws = ctx.workspace(lib.pmd_tiles_workspace_bytes(n_loc, b1, b2, P_pool, r, a_f, crop, ldv, Dl))
+            ctx.call("pmd_tiles_decompose", ptr(xf), ld_f, Dl, crop, ptr(pix_loc_dev), n_loc, b1, b2, ptr(pool_q_dev),
                      pool_q.shape[1], P_pool, ptr(pool_idx_dev), ptr(pool_w_dev), r, a_f, thr_s32, thr_t32,
                      int(max_consecutive_failures), seed, t_lo, 1, ptr(ut_dev[t_lo:]), ptr(v_dev[t_lo:]), ldv,
                      ptr(stats_dev[t_lo:]), ptr(good_dev[t_lo:]), ptr(keep_dev[t_lo:]), ptr(ranks_dev[t_lo:]),
@@ -460,23 +503,23 @@ def localmd_decomposition(
             gd_w = torch.zeros((n_loc, 64), dtype=torch.int32, device=ctx.device)
             kp_w = torch.zeros((n_loc, 64), dtype=torch.int32, device=ctx.device)
             for widx, w0 in enumerate(win_starts):
-                xw[:D, :win_len] = xf[:D, w0:w0 + win_len]
+                xw[:Dl, :win_len] = xf[:Dl, w0:w0 + win_len]
                 if widx == 0:
-                    ws = ctx.workspace(lib.pmd_tiles_workspace_bytes(n_loc, b1, b2, P_pool, r, a_f, win_len, ld_w, D))
-                    ctx.call("pmd_tiles_decompose", ptr(xw), ld_w, D, win_len, ptr(pix_dev[t_lo:]), n_loc, b1, b2,
+                    ws = ctx.workspace(lib.pmd_tiles_workspace_bytes(n_loc, b1, b2, P_pool, r, a_f, win_len, ld_w, Dl))
+                    ctx.call("pmd_tiles_decompose", ptr(xw), ld_w, Dl, win_len, ptr(pix_loc_dev), n_loc, b1, b2,
                              ptr(pool_q_dev), pool_q.shape[1], P_pool, ptr(pool_idx_dev), ptr(pool_w_dev), r, a_f, thr_s32,
                              thr_t32, int(max_consecutive_failures), seed, t_lo * n_win, n_win, ptr(ut_dev[t_lo:]), ptr(vw),
                              ld_w, ptr(stats_dev[t_lo:]), ptr(good_dev[t_lo:]), ptr(keep_dev[t_lo:]), ptr(ranks_dev[t_lo:]),
                              ptr(lam_dev[t_lo:]), ptr(ws), ws.numel())
                     ctx.call("pmd_tiles_truncate", ptr(ut_dev[t_lo:]), dpad, ptr(ranks_dev[t_lo:]), n_loc)
                 else:
-                    ws = ctx.workspace(lib.pmd_tiles_residual_workspace_bytes(n_loc, b1, b2, r, a_f, win_len, D))
-                    ctx.call("pmd_tiles_residual", ptr(xw), ld_w, D, win_len, ptr(pix_dev[t_lo:]), n_loc, b1, b2, r, a_f,
+                    ws = ctx.workspace(lib.pmd_tiles_residual_workspace_bytes(n_loc, b1, b2, r, a_f, win_len, Dl))
+                    ctx.call("pmd_tiles_residual", ptr(xw), ld_w, Dl, win_len, ptr(pix_loc_dev), n_loc, b1, b2, r, a_f,
                              thr_s32, thr_t32, int(max_consecutive_failures), seed, t_lo * n_win + widx, n_win,
                              ptr(ut_dev[t_lo:]), ptr(ranks_dev[t_lo:]), ptr(st_w), ptr(gd_w), ptr(kp_w), ptr(ws), ws.numel())
             del xw, vw
             # temporal traces over all fitted frames: U_b^T X (get_temporal_projector, decomposition.py:518-523)
-            ctx.call("pmd_tiles_project", ptr(xf), ld_f, crop, ptr(pix_dev[t_lo:]), n_loc, d, ptr(ut_dev[t_lo:]), dpad,
+            ctx.call("pmd_tiles_project", ptr(xf), ld_f, crop, ptr(pix_loc_dev), n_loc, d, ptr(ut_dev[t_lo:]), dpad,
                      ptr(v_dev[t_lo:]), ldv, 2)
         for tns in (ut_dev, stats_dev, good_dev, keep_dev, ranks_dev, lam_dev):
             dist.gather_runs(tns, runs)
@@ -588,26 +631,32 @@ def localmd_decomposition(
         row_lo, row_hi = 0, Rc
         Z = W1 = None
 
-        def build_z(a0, an):
-            """Z = (U W)^T ((Y - mean) / std) over the whole movie for tiles [a0, a0 + an) (pmd_loader.py:316-346);
-            the K background rows are always filled."""
+        def build_z(everywhere):
+            """Z = (U W)^T ((Y - mean) / std) over the whole movie (pmd_loader.py:316-346).  A rank projects the tiles
+            of its own run (it holds no other pixels); everywhere=True then collects all rows on every rank (the
+            replicated global stage), otherwise a rank keeps only its own rows (row-sharded stage).  The K
+            background rows are filled on every rank."""
             if all_frames and ldv == ld_T:
                 proj = v_dev     # same shape; the fit-frame traces are already compacted into v_cropped
             else:
                 proj = torch.empty((n_tiles, 64, ld_T), dtype=torch.float32, device=ctx.device)
             z = torch.zeros((Rc, T), dtype=torch.float32, device=ctx.device)
-            if an > 0:
-                ctx.call("pmd_tiles_project", ptr(xs_full), ld_T, T, ptr(pix_dev[a0:]), an, d, ptr(uw_dev[a0:]), dpad,
-                         ptr(proj[a0:]), ld_T, 2)
-                ctx.call("pmd_compact_rows", ptr(proj[a0:]), ld_T, ptr(col_off_dev[a0:]), ptr(ranks_dev[a0:]), T, ptr(z), T, an)
+            if n_loc > 0:
+                ctx.call("pmd_tiles_project", ptr(xs_full), ld_T, T, ptr(pix_loc_dev), n_loc, d, ptr(uw_dev[t_lo:]), dpad,
+                         ptr(proj[t_lo:]), ld_T, 2)
+                ctx.call("pmd_compact_rows", ptr(proj[t_lo:]), ld_T, ptr(col_off_dev[t_lo:]), ptr(ranks_dev[t_lo:]), T, ptr(z), T,
+                         n_loc)
+            if everywhere:
+                dist.gather_runs(z, [(int(offsets[lo]), int(offsets[hi])) for lo, hi in runs])
             if K > 0:
                 if all_frames:
                     z[Rt:Rt + K, :] = pj_dev[:, :T]
                 else:
                     pj_full = torch.zeros((K, ld_T), dtype=torch.float32, device=ctx.device)
-                    ws_ = ctx.workspace(lib.pmd_bg_project_workspace_bytes(D, T))
-                    ctx.call("pmd_bg_project", ptr(xs_full), D, T, ld_T, ptr(basis_dev), K, ptr(pj_full), ld_T, ptr(ws_),
-                             ws_.numel())
+                    ws_ = ctx.workspace(lib.pmd_bg_project_workspace_bytes(O_hi - O_lo, T))
+                    ctx.call("pmd_bg_project", ptr(xs_full[O_lo - P_lo:]), O_hi - O_lo, T, ld_T, ptr(basis_dev[O_lo:]), K,
+                             ptr(pj_full), ld_T, ptr(ws_), ws_.numel())
+                    dist.all_reduce(pj_full)
                     z[Rt:Rt + K, :] = pj_full[:, :T]
             return z
 
@@ -677,7 +726,7 @@ def localmd_decomposition(
                 ev_c.record(main)
                 lap("orthogonalize", t0)
                 t0 = time.perf_counter()
-                Z = build_z(t_lo, n_loc) if shard else build_z(0, n_tiles)
+                Z = build_z(everywhere=not shard)
                 W1 = torch.zeros((m_eff, T), dtype=torch.float32, device=ctx.device)
                 if nrow > 0:
                     Mt = torch.empty((m_eff, nrow), dtype=torch.float32, device=ctx.device)
@@ -731,7 +780,7 @@ def localmd_decomposition(
         t0 = time.perf_counter()
         shard = shard and use_right and chol_ok and rp <= T
         if Z is None:
-            Z = build_z(0, n_tiles)
+            Z = build_z(everywhere=True)
         _dbg("Z", Z)
         lap("v_projection", t0)
 
@@ -842,6 +891,14 @@ def localmd_decomposition(
         lap("d2h_results", t0)
         display("Matrix decomposition completed")
 
+        if dist.enabled:
+            mean_all = torch.zeros(D, dtype=torch.float32, device=ctx.device)
+            std_all = torch.zeros(D, dtype=torch.float32, device=ctx.device)
+            mean_all[O_lo:O_hi] = mean_dev[O_lo - P_lo:O_hi - P_lo]
+            std_all[O_lo:O_hi] = std_dev[O_lo - P_lo:O_hi - P_lo]
+            dist.gather_runs(mean_all, owned)
+            dist.gather_runs(std_all, owned)
+            mean_dev, std_dev = mean_all, std_all
         mean_img = mean_dev.cpu().numpy().reshape(d1, d2)
         std_img = std_dev.cpu().numpy().reshape(d1, d2)
         final_movie = None if root_only else PMDArray(u_r, r_mat, s, vt, (T, d1, d2), order, mean_img, std_img)

@@ -48,6 +48,16 @@ class Dist:
                 dist.broadcast(tensor[lo:hi], src=dist.get_global_rank(self.group, r) if self.group is not None else r,
                                group=self.group)
 
+    def broadcast_object(self, obj):
+        """Rank 0's value of a small Python object on every rank (seeds, the random frame sample)."""
+        if not self.enabled:
+            return obj
+        import torch.distributed as dist
+
+        box = [obj]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+        return box[0]
+
     def all_reduce(self, tensor):
         """In-place sum over the ranks (RCCL all-reduce on GPUs)."""
         if not self.enabled:
