@@ -96,7 +96,13 @@ def main():
     Dm.QUIET = True
     cfg = CONFIGS[args.config]
     device = torch.device("cuda", local_rank)
-    movie = make_movie_torch(cfg["T"], cfg["d1"], cfg["d2"], device, seed=0)
+    if world > 1:
+        # every rank builds only the pixel slab of its band of tile rows (same values as the single-GPU movie)
+        from localmd_amd.synthetic import SyntheticSlabSource
+
+        movie = SyntheticSlabSource(cfg["T"], cfg["d1"], cfg["d2"], device, seed=0)
+    else:
+        movie = make_movie_torch(cfg["T"], cfg["d1"], cfg["d2"], device, seed=0)
     ctx = Context(local_rank)
     seed = 2024
 

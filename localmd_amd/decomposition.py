@@ -93,7 +93,10 @@ class _Movie:
         self.T, self.d1, self.d2 = shape
         i_lo, i_hi = (0, self.d1) if rows is None else rows
         self.D = (i_hi - i_lo) * self.d2
-        if isinstance(dataset_obj, torch.Tensor):
+        if hasattr(dataset_obj, "slab"):   # a source that can build a band of FOV rows on the device
+            mv = dataset_obj.slab(i_lo, i_hi).to(device=ctx.device, dtype=torch.float32)
+            self.dev = mv.reshape(self.T, self.D).contiguous()
+        elif isinstance(dataset_obj, torch.Tensor):
             mv = dataset_obj[:, i_lo:i_hi, :].to(device=ctx.device, dtype=torch.float32)
             self.dev = mv.reshape(self.T, self.D).contiguous()
         else:

@@ -47,24 +47,29 @@ def make_movie(T, d1, d2, seed=0, noise=1.0, dtype=np.float32):
     return movie.astype(dtype)
 
 
-def make_movie_torch(T, d1, d2, device, seed=0, noise=1.0, strip=64):
+def make_movie_torch(T, d1, d2, device, seed=0, noise=1.0, strip=64, rows=None):
     """Same model on ``device`` (float32, (T, d1, d2)); sources drawn on host with the same
-    generator as ``make_movie``; noise from torch's device generator."""
+    generator as ``make_movie``; noise from torch's device generator, re-seeded per strip of 64 FOV rows so
+    that any band of rows can be generated on its own: rows=(i_lo, i_hi) returns exactly
+    make_movie_torch(...)[:, i_lo:i_hi, :] without building the rest."""
     import torch
 
     rng = np.random.Generator(np.random.PCG64(seed))
     ci, cj, peak, traces = _sources(d1, d2, T, rng)
     g = torch.Generator(device=device)
-    g.manual_seed(seed)
+    r_lo, r_hi = (0, d1) if rows is None else (int(rows[0]), int(rows[1]))
     tr = torch.from_numpy(traces).to(device)  # (n, T)
     ci_t = torch.from_numpy(ci.astype(np.float32)).to(device)
     cj_t = torch.from_numpy(cj.astype(np.float32)).to(device)
     pk_t = torch.from_numpy(peak.astype(np.float32)).to(device)
     slow = 0.5 * torch.sin(2 * math.pi * torch.arange(T, device=device, dtype=torch.float32) / 1000.0)
     jj = torch.arange(d2, device=device, dtype=torch.float32)
-    movie = torch.empty((T, d1, d2), device=device, dtype=torch.float32)
+    movie = torch.empty((T, r_hi - r_lo, d2), device=device, dtype=torch.float32)
     for i0 in range(0, d1, strip):
         i1 = min(d1, i0 + strip)
+        if i1 <= r_lo or i0 >= r_hi:
+            continue
+        g.manual_seed(int(seed) * 1000003 + i0)
         ii = torch.arange(i0, i1, device=device, dtype=torch.float32)
         near = ((ci_t > i0 - 12) & (ci_t < i1 + 12)).nonzero().flatten()
         di = ii[None, :, None] - ci_t[near, None, None]
@@ -76,6 +81,26 @@ def make_movie_torch(T, d1, d2, device, seed=0, noise=1.0, strip=64):
         block += slow[:, None, None] * ramp[None]
         block += 100.0
         block += noise * torch.randn(block.shape, device=device, dtype=torch.float32, generator=g)
-        movie[:, i0:i1, :] = block
+        a, b = max(i0, r_lo), min(i1, r_hi)
+        movie[:, a - r_lo:b - r_lo, :] = block[:, a - i0:b - i0, :]
         del block, foot, di, dj
     return movie
+
+
+class SyntheticSlabSource:
+    """The synthetic movie as a dataset that never exists as a whole: ``shape`` plus ``slab(i_lo, i_hi)``,
+    which builds the FOV rows [i_lo, i_hi) on the device.  localmd_decomposition(distributed=True) asks every
+    rank only for the slab of its band of tile rows (BASELINE configs 4 and 5 do not fit one GPU otherwise)."""
+
+    def __init__(self, T, d1, d2, device, seed=0, noise=1.0):
+        self.shape = (int(T), int(d1), int(d2))
+        self.device, self.seed, self.noise = device, seed, noise
+        self._cache = None
+
+    def slab(self, i_lo, i_hi):
+        """The rows stay resident after the first request (the data set of a benchmark lives in HBM)."""
+        key = (int(i_lo), int(i_hi))
+        if self._cache is None or self._cache[0] != key:
+            T, d1, d2 = self.shape
+            self._cache = (key, make_movie_torch(T, d1, d2, self.device, seed=self.seed, noise=self.noise, rows=key))
+        return self._cache[1]

@@ -138,3 +138,15 @@ def test_large_tiles_1024x1024_b32(gpu_ctx):
     assert len(diag["tile_ranks"]) == 63 * 63
     _check_properties(pmd, diag, noisy, T, d1, d2, block)
     gpu_ctx.release_workspace()
+
+
+def test_synthetic_slab_source_matches_whole_movie(gpu_ctx):
+    """A band of FOV rows generated on its own equals the same rows of the whole synthetic movie."""
+    import torch
+    from localmd_amd.synthetic import make_movie_torch, SyntheticSlabSource
+
+    dev = gpu_ctx.device
+    whole = make_movie_torch(300, 200, 90, dev, seed=3)
+    src = SyntheticSlabSource(300, 200, 90, dev, seed=3)
+    for lo, hi in ((0, 200), (0, 70), (50, 130), (128, 200), (63, 65)):
+        assert torch.equal(src.slab(lo, hi), whole[:, lo:hi, :])
