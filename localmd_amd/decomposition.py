@@ -399,14 +399,17 @@ def localmd_decomposition(
         display("Running Simulations, block dimensions are {} x {} x {} ".format(b1, b2, window_chunks))
         t0 = time.perf_counter()
         sim_stats = None
+        sim_pending = None
         if thresholds is None:
-            ws = ctx.workspace(lib.pmd_threshold_sim_workspace_bytes(b1, b2, int(window_chunks), int(sim_iters)))
-            stats_dev = torch.empty((sim_iters, 2), dtype=torch.float32, device=ctx.device)
-            ctx.call("pmd_threshold_sim", b1, b2, int(window_chunks), int(sim_iters), seed, ptr(stats_dev), ptr(ws), ws.numel())
-            ctx.sync()
-            sim_stats = stats_dev.cpu().numpy()
-            spatial_threshold = np.percentile(sim_stats[:, 0], sim_conf)
-            temporal_threshold = np.percentile(sim_stats[:, 1], sim_conf)
+            # The simulation depends on nothing but the block shape: it runs on the second stream, next to the
+            # HBM-bound standardise / filter passes below; its result is fetched right before the tile stage.
+            sc = ctx.side()
+            with torch.cuda.stream(sc.stream):
+                ws_sim = sc.workspace(lib.pmd_threshold_sim_workspace_bytes(b1, b2, int(window_chunks), int(sim_iters)))
+                sim_dev = torch.empty((sim_iters, 2), dtype=torch.float32, device=ctx.device)
+                sc.call("pmd_threshold_sim", b1, b2, int(window_chunks), int(sim_iters), seed, ptr(sim_dev), ptr(ws_sim),
+                        ws_sim.numel())
+            sim_pending = (sc, sim_dev)
         else:
             spatial_threshold, temporal_threshold = thresholds
         lap("simulation", t0)
@@ -487,6 +490,12 @@ def localmd_decomposition(
         n_loc = t_hi - t_lo
         # pixel lists of this rank's tiles relative to its slab (the kernels that read the movie copies)
         pix_loc_dev = _i32(ctx, pix_c[t_lo:t_hi] - P_lo) if dist.enabled else pix_dev
+        if sim_pending is not None:
+            sim_pending[0].sync()
+            sim_stats = sim_pending[1].cpu().numpy()
+            spatial_threshold = np.percentile(sim_stats[:, 0], sim_conf)
+            temporal_threshold = np.percentile(sim_stats[:, 1], sim_conf)
+            sim_pending = None
         thr_s32, thr_t32 = float(np.float32(spatial_threshold)), float(np.float32(temporal_threshold))
         a_f = int(temporal_avg_factor)
         if n_loc > 0 and n_win == 1:
