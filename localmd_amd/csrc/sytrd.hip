@@ -702,7 +702,7 @@ int pmd_syevd(pmd_ctx* ctx, int n, float* A, long lda, float* w, float* work, in
   const char* mode = getenv("PMD_SYEVD");
   const bool force_lib = mode && !strcmp(mode, "rocsolver");
   const bool force_own = mode && !strcmp(mode, "own");
-  const bool own = !force_lib && (force_own || n >= 1024) && n >= 3 && lda % 4 == 0 && lda >= pmd_round_up(n, 4) && !((uintptr_t)A & 15);
+  const bool own = !force_lib && (force_own || n >= 192) && n >= 3 && lda % 4 == 0 && lda >= pmd_round_up(n, 4) && !((uintptr_t)A & 15);
   if (!own) {
     pmd_prof_scope prof__(ctx, "rocsolver_ssyevd");
     PMD_BLAS(ctx, rocsolver_ssyevd(ctx->blas, rocblas_evect_original, rocblas_fill_lower, n, A, (rocblas_int)lda, w, work, info));

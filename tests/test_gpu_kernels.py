@@ -383,7 +383,7 @@ def test_sytrd_eigenvalues_2500(gpu_ctx):
     np.testing.assert_array_equal(e, e2)
 
 
-@pytest.mark.parametrize("n,force", [(301, True), (1200, False)])
+@pytest.mark.parametrize("n,force", [(150, True), (301, False), (1200, False)])
 def test_syevd_own_path(gpu_ctx, n, force, monkeypatch):
     torch = _t()
     ctx = gpu_ctx
