@@ -604,12 +604,12 @@ int pmd_sytrd_impl(pmd_ctx* ctx, int n, float* A, long lda, float* d, float* e, 
   B.scal = ar.take_n<float>(16);
   if (ar.overflow) return pmd_fail(ctx, PMD_ERR_WORKSPACE, "pmd_sytrd", "workspace too small");
   hipStream_t st = ctx->stream;
-  const char* cwenv = getenv("PMD_SYMV_CW512_BELOW");
-  const int cw512_below = cwenv ? atoi(cwenv) : 1 << 30;
   const char* s2k = getenv("PMD_SYR2K");
   const bool use_rocblas_syr2k = s2k && !strcmp(s2k, "rocblas");
   const char* cwf = getenv("PMD_SYMV_CW");
-  const int cw_fixed = cwf ? atoi(cwf) : 512;  // measured at n = 10^4: 334 ms (1024), 303 ms (512), 320 ms (256)
+  // symv tile width: 512 (two workgroups per CU); measured at n = 10^4: 334 ms (1024), 303 ms (512), 320 ms (256)
+  int cw_fixed = cwf ? atoi(cwf) : 512;
+  if (cw_fixed != 256 && cw_fixed != 512 && cw_fixed != 1024) cw_fixed = 512;
   B.cw = CW;
   const float one = 1.f, minus1 = -1.f;
   int nsp = 0;
@@ -626,8 +626,7 @@ int pmd_sytrd_impl(pmd_ctx* ctx, int n, float* A, long lda, float* d, float* e, 
       const int nbk = (n - cs + BR - 1) / BR;
       const int npairs = (nbk + 1) / 2;
       auto r0 = [&](int b) { return (cs + b * BR) & ~3; };
-      // narrower tiles (twice the workgroups, two per CU) below cw512_below trailing rows
-      const int cw = cw_fixed ? cw_fixed : ((n - cs < cw512_below) ? 512 : CW);
+      const int cw = cw_fixed;
       auto nq = [&](int b) { return (n - r0(b) + cw - 1) / cw; };
       int nqx = 1;
       for (int p = 0; p < npairs; ++p) nqx = std::max(nqx, nq(p) + ((nbk - 1 - p != p) ? nq(nbk - 1 - p) : 0));
