@@ -447,3 +447,10 @@ def test_full_pipeline_assorted_shapes(gpu_ctx, case):
         _check_full(pmd, diag, ref, mov, vt_tol=5e-3, orth_tol=1e-2, s_tol=3e-3, vt_tol_signal=2e-3)
     else:
         _check_full(pmd, diag, ref, mov, vt_tol=3e-3)
+
+
+def test_full_pipeline_long_time_axis(gpu_ctx):
+    """T = 5000 frames (five Welch chunks, 500 temporal bins per tile, 157 time chunks in the tile GEMMs)."""
+    mov = _movie(5000, 40, 40, seed=11)
+    pmd, diag, ref = _compare_full(gpu_ctx, mov, (20, 20), 5000, max_components=8, background_rank=3, sim_iters=8)
+    _check_full(pmd, diag, ref, mov, vt_tol=3e-3)
