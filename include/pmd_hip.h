@@ -102,6 +102,20 @@ int pmd_tiles_decompose(pmd_ctx* ctx, const float* xf, long ldx, long n_rows, in
                         int a, float thr_s, float thr_t, int max_fail, uint64_t seed, uint32_t omega_index0,
                         uint32_t omega_index_step, float* Ut_out, float* V_out, long ldv, float* stats_out,
                         int* good_out, int* keep_out, int* ranks_out, double* lam_out, void* ws, size_t ws_bytes);
+/* The same pipeline in three resumable parts, for the reference's denoiser hooks (arbitrary callables inside
+ * single_block_md).  stages is a mask: bit 0 = up to V_ds = U_ds^T X_ds (decomposition.py:279-298); the
+ * temporal_denoiser (:300) then acts on V_ds[n][64][ldv] (rows < r, t_crop frames) at byte offset *vds_offset of
+ * the workspace; bit 1 = basis of its row space and S = X V_b^T (:301-306); the spatial_denoiser (:310) acts on
+ * S[n][64][dpad] (row c = component c, tile pixel il + b1*jl) at *s_offset; bit 2 = the rest (:315-328 and the
+ * keep/discard scan).  The workspace must be left untouched between the calls except for the hook arrays. */
+int pmd_tiles_decompose_staged(pmd_ctx* ctx, const float* xf, long ldx, long n_rows, int t_crop, const int* tile_pix, int n_tiles,
+                               int b1, int b2, const int* pool_q, int pool_max, int P, const int* pool_idx,
+                               const float* pool_w, int r, int a, float thr_s, float thr_t, int max_fail, uint64_t seed,
+                               uint32_t omega_index0, uint32_t omega_index_step, float* Ut_out, float* V_out, long ldv,
+                               float* stats_out, int* good_out, int* keep_out, int* ranks_out, double* lam_out, void* ws,
+                               size_t ws_bytes, int stages);
+int pmd_tiles_hook_offsets(int n_tiles, int b1, int b2, int P, int r, int a, int t_crop, long ldv, long n_rows,
+                           size_t* vds_offset, size_t* s_offset);
 
 /* A9: one further temporal window (decomposition.py:333-387 single_residual_block_md, :489-515): xw = the
  * window's frames (pixel-major, L frames); Ucur[n][64][dpad] holds counts[tile] components (other rows zero)

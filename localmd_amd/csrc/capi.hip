@@ -170,7 +170,24 @@ int pmd_tiles_decompose(pmd_ctx* ctx, const float* xf, long ldx, long n_rows, in
   CTX_CHECK(ctx);
   return pmd_tiles_decompose_impl(ctx, xf, ldx, n_rows, t_crop, tile_pix, n_tiles, b1, b2, pool_q, pool_max, P, pool_idx,
                                   pool_w, r, a, thr_s, thr_t, max_fail, seed, omega_index0, omega_index_step, Ut_out,
-                                  V_out, ldv, stats_out, good_out, keep_out, ranks_out, lam_out, ws, ws_bytes);
+                                  V_out, ldv, stats_out, good_out, keep_out, ranks_out, lam_out, ws, ws_bytes, 7);
+}
+int pmd_tiles_decompose_staged(pmd_ctx* ctx, const float* xf, long ldx, long n_rows, int t_crop, const int* tile_pix, int n_tiles,
+                               int b1, int b2, const int* pool_q, int pool_max, int P, const int* pool_idx,
+                               const float* pool_w, int r, int a, float thr_s, float thr_t, int max_fail, uint64_t seed,
+                               uint32_t omega_index0, uint32_t omega_index_step, float* Ut_out, float* V_out, long ldv,
+                               float* stats_out, int* good_out, int* keep_out, int* ranks_out, double* lam_out, void* ws,
+                               size_t ws_bytes, int stages) {
+  CTX_CHECK(ctx);
+  if (stages < 1 || stages > 7) return pmd_fail(ctx, PMD_ERR_ARG, "pmd_tiles_decompose_staged", "stages must be a mask of bits 0..2");
+  return pmd_tiles_decompose_impl(ctx, xf, ldx, n_rows, t_crop, tile_pix, n_tiles, b1, b2, pool_q, pool_max, P, pool_idx,
+                                  pool_w, r, a, thr_s, thr_t, max_fail, seed, omega_index0, omega_index_step, Ut_out,
+                                  V_out, ldv, stats_out, good_out, keep_out, ranks_out, lam_out, ws, ws_bytes, stages);
+}
+int pmd_tiles_hook_offsets(int n_tiles, int b1, int b2, int P, int r, int a, int t_crop, long ldv, long n_rows,
+                           size_t* vds_offset, size_t* s_offset) {
+  if (!vds_offset || !s_offset) return PMD_ERR_ARG;
+  return pmd_tiles_hook_offsets_impl(n_tiles, b1 * b2, P, r, a, t_crop, ldv, n_rows, vds_offset, s_offset);
 }
 
 size_t pmd_tiles_residual_workspace_bytes(int n_tiles, int b1, int b2, int r, int a, int L, long n_rows) {

@@ -72,7 +72,8 @@ int pmd_tiles_decompose_impl(pmd_ctx* ctx, const float* Xf, long ldx, long n_row
                              int b2, const int* pool_q, int pool_max, int P, const int* pool_idx, const float* pool_w,
                              int r, int a, float thr_s, float thr_t, int max_fail, uint64_t seed, uint32_t omega_index0,
                              uint32_t omega_index_step, float* Ut_out, float* V_out, long ldv, float* stats_out,
-                             int* good_out, int* keep_out, int* ranks_out, double* sing_out, void* ws, size_t ws_bytes) {
+                             int* good_out, int* keep_out, int* ranks_out, double* sing_out, void* ws, size_t ws_bytes,
+                             int stages) {
   const int d = b1 * b2;
   if (r < 1 || r + 10 > 64) return pmd_fail(ctx, PMD_ERR_UNSUPPORTED, "pmd_tiles_decompose", "max_components must be in [1, 54]");
   if (a < 1 || t_crop % a != 0 || t_crop / a < 1) return pmd_fail(ctx, PMD_ERR_ARG, "pmd_tiles_decompose", "t_crop must be a positive multiple of temporal_avg_factor");
@@ -86,6 +87,9 @@ int pmd_tiles_decompose_impl(pmd_ctx* ctx, const float* Xf, long ldx, long n_row
   if (r > p.nref) return pmd_fail(ctx, PMD_ERR_ARG, "pmd_tiles_decompose", "max_components exceeds pooled pixel count");
   const long s64d = 64L * p.dpad, s64P = 64L * p.Ppad, s64b = 64L * p.ld_b, s64v = 64L * ldv;
 
+  // stages: bit 0 = up to V_ds (p.outA; the temporal_denoiser hook of decomposition.py:300 acts on it),
+  //         bit 1 = basis of its row space and S = X V_b^T (p.sst; spatial_denoiser hook, :310), bit 2 = the rest
+  if (stages & 1) {
   PMD_HIP(ctx, hipMemsetAsync(ws, 0, p.zero_bytes, ctx->stream));
   PMD_HIP(ctx, hipMemsetAsync(Ut_out, 0, (size_t)n * s64d * sizeof(float), ctx->stream));
 
@@ -107,6 +111,9 @@ int pmd_tiles_decompose_impl(pmd_ctx* ctx, const float* Xf, long ldx, long n_row
   // --- V_ds = U_ds^T X_ds; basis of its row space (decomposition.py:295-301)
   ctx->atx_label = "tile_atx_main";
   RUN(pmd_launch_tile_atx(ctx, Xf, ldx, tile_pix, d, 0, d, p.ut0, s64d, p.dpad, p.outA, s64v, ldv, n, t_crop, 2));
+  ctx->atx_label = nullptr;
+  }
+  if (stages & 2) {
   // (this Gram only conditions the basis change -- span(S) does not depend on it -- so fp32 MFMA is enough)
   RUN(pmd_launch_tile_xbt(ctx, p.outA, ldv, nullptr, 0, 64, 64, p.outA, s64v, ldv, p.g1f, GRAM_SLICES * 4096L, 4096, 64, n, t_crop, GRAM_SLICES));
   RUN(pmd_launch_gram_f2d(ctx, p.g1f, 64, (long)n * GRAM_SLICES, p.gpart));
@@ -116,11 +123,14 @@ int pmd_tiles_decompose_impl(pmd_ctx* ctx, const float* Xf, long ldx, long n_row
   RUN(pmd_launch_tile_xbt(ctx, Xf, ldx, tile_pix, d, 0, d, p.outA, s64v, ldv, p.spart, XBT_SLICES * s64d, s64d, p.dpad, n, t_crop, XBT_SLICES));
   RUN(pmd_launch_reduce_slices(ctx, p.spart, XBT_SLICES * s64d, s64d, XBT_SLICES, s64d, p.sst, s64d, n));
   RUN(pmd_launch_tile_rowmix(ctx, p.sst, s64d, p.dpad, p.nmat, 4096, r, r, p.sst, s64d, p.dpad, d, n));
+  }
+  if (stages & 4) {
   RUN(pmd_launch_tile_gram(ctx, p.sst, s64d, p.dpad, d, n, 1, p.gpart));
   RUN(pmd_launch_small_eig(ctx, p.gpart, 1, r, 1, 1e-10, p.nmat, p.lam, n));
   RUN(pmd_launch_tile_rowmix(ctx, p.sst, s64d, p.dpad, p.nmat, 4096, r, r, p.sst, s64d, p.dpad, d, n));
 
   // --- W = U0^T X, its SVD rotates U0 and gives sigma*V (decomposition.py:318-323)
+  ctx->atx_label = "tile_atx_main";
   RUN(pmd_launch_tile_atx(ctx, Xf, ldx, tile_pix, d, 0, d, p.sst, s64d, p.dpad, V_out, s64v, ldv, n, t_crop, 2));
   ctx->atx_label = nullptr;
   RUN(pmd_launch_tile_gram(ctx, V_out, s64v, ldv, t_crop, n, GRAM_SLICES, p.gpart));
@@ -131,6 +141,17 @@ int pmd_tiles_decompose_impl(pmd_ctx* ctx, const float* Xf, long ldx, long n_row
   // --- roughness statistics and keep/discard scan (evaluation.py:84-222)
   RUN(pmd_launch_stats_roughness(ctx, Ut_out, s64d, p.dpad, b1, b2, V_out, s64v, ldv, t_crop, r, stats_out, n));
   RUN(pmd_launch_decide(ctx, stats_out, r, thr_s, thr_t, max_fail, r, n, good_out, keep_out, ranks_out));
+  }
+  return PMD_OK;
+}
+
+int pmd_tiles_hook_offsets_impl(int n, int d, int P, int r, int a, int t_crop, long ldv, long n_rows, size_t* vds_off,
+                                size_t* s_off) {
+  pmd_arena ar((void*)0x1000, ~size_t(0) >> 1);
+  tiles_plan p;
+  if (plan_tiles(ar, p, n, d, P, r, a, t_crop, ldv, n_rows) != PMD_OK) return PMD_ERR_UNSUPPORTED;
+  *vds_off = (size_t)((char*)p.outA - (char*)0x1000);
+  *s_off = (size_t)((char*)p.sst - (char*)0x1000);
   return PMD_OK;
 }
 

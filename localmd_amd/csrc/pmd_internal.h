@@ -60,7 +60,10 @@ int pmd_tiles_decompose_impl(pmd_ctx* ctx, const float* Xf, long ldx, long n_row
                              int b2, const int* pool_q, int pool_max, int P, const int* pool_idx, const float* pool_w,
                              int r, int a, float thr_s, float thr_t, int max_fail, uint64_t seed, uint32_t omega_index0,
                              uint32_t omega_index_step, float* Ut_out, float* V_out, long ldv, float* stats_out,
-                             int* good_out, int* keep_out, int* ranks_out, double* sing_out, void* ws, size_t ws_bytes);
+                             int* good_out, int* keep_out, int* ranks_out, double* sing_out, void* ws, size_t ws_bytes,
+                             int stages);
+int pmd_tiles_hook_offsets_impl(int n, int d, int P, int r, int a, int t_crop, long ldv, long n_rows, size_t* vds_off,
+                                size_t* s_off);
 size_t pmd_sim_workspace_bytes_impl(int d, int t, int iters);
 int pmd_threshold_sim_impl(pmd_ctx* ctx, int b1, int b2, int t, int iters, uint64_t seed, float* stats_out, void* ws,
                            size_t ws_bytes);

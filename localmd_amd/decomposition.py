@@ -180,6 +180,51 @@ def _sparse_u(ut_host, ranks, pix_f, block_weights, inv_cumw_rows, n_rows):
     return u_r, offsets
 
 
+def _apply_hook(fn, arr):
+    """arr: (n_tiles, ...) device view.  The reference calls the denoiser once per block (decomposition.py:300, :310);
+    a callable with a true ``batched`` attribute receives all tiles at once instead."""
+    torch = _torch()
+    if getattr(fn, "batched", False):
+        out = fn(arr.contiguous())
+        if tuple(out.shape) != tuple(arr.shape):
+            raise ValueError("denoiser returned shape {} for input {}".format(tuple(out.shape), tuple(arr.shape)))
+        arr.copy_(torch.as_tensor(out, dtype=torch.float32, device=arr.device))
+        return
+    for i in range(arr.shape[0]):
+        out = fn(arr[i].contiguous())
+        if tuple(out.shape) != tuple(arr[i].shape):
+            raise ValueError("denoiser returned shape {} for input {}".format(tuple(out.shape), tuple(arr[i].shape)))
+        arr[i].copy_(torch.as_tensor(out, dtype=torch.float32, device=arr.device))
+
+
+def _tiles_decompose(ctx, args, ws, hook_geom, temporal_denoiser, spatial_denoiser):
+    """pmd_tiles_decompose, or its three resumable parts around the denoiser hooks of single_block_md
+    (decomposition.py:300 temporal_denoiser on V_ds (r, t); :304-313 spatial_denoiser on S as (r, b1, b2)).
+    The hooks get float32 device tensors (torch) and must return tensors of the same shape."""
+    torch = _torch()
+    if temporal_denoiser is None and spatial_denoiser is None:
+        ctx.call("pmd_tiles_decompose", *args, ptr(ws), ws.numel())
+        return
+    n, b1, b2, P_pool, r, a_f, t_crop, ldv, n_rows, dpad = hook_geom
+    import ctypes as C
+
+    off_v, off_s = C.c_size_t(0), C.c_size_t(0)
+    rc = ctx.lib.pmd_tiles_hook_offsets(n, b1, b2, P_pool, r, a_f, t_crop, ldv, n_rows, C.byref(off_v), C.byref(off_s))
+    if rc != 0:
+        raise ValueError("pmd_tiles_hook_offsets failed ({})".format(rc))
+    flat = ws.view(torch.uint8).reshape(-1)
+    vds = flat[off_v.value:off_v.value + n * 64 * ldv * 4].view(torch.float32).view(n, 64, ldv)[:, :r, :t_crop]
+    s_arr = flat[off_s.value:off_s.value + n * 64 * dpad * 4].view(torch.float32).view(n, 64, dpad)[:, :r, :b1 * b2]
+    ctx.call("pmd_tiles_decompose_staged", *args, ptr(ws), ws.numel(), 1)
+    if temporal_denoiser is not None:
+        _apply_hook(temporal_denoiser, vds)
+    ctx.call("pmd_tiles_decompose_staged", *args, ptr(ws), ws.numel(), 2)
+    if spatial_denoiser is not None:
+        # tile pixel q = il + b1 * jl  ->  (r, b1, b2) as the reference's F-order reshape + transpose(2, 0, 1)
+        _apply_hook(spatial_denoiser, s_arr.view(n, r, b2, b1).transpose(2, 3))
+    ctx.call("pmd_tiles_decompose_staged", *args, ptr(ws), ws.numel(), 4)
+
+
 def _orthogonalize(ctx, G, R, M, m, ldm):
     """Device A15.  Returns (P tensor (R, ldp), R')."""
     torch = _torch()
@@ -288,8 +333,9 @@ def localmd_decomposition(
     torch = _torch()
     if np.dtype(dtype) != np.float32:
         raise ValueError("only dtype='float32' is supported (the reference computes in float32 throughout)")
-    if spatial_denoiser is not None or temporal_denoiser is not None:
-        raise NotImplementedError("spatial_denoiser / temporal_denoiser hooks are not available in the HIP pipeline")
+    for hook in (spatial_denoiser, temporal_denoiser):
+        if hook is not None and not callable(hook):
+            raise TypeError("spatial_denoiser / temporal_denoiser must be callables on torch device tensors")
     if order not in ("F", "C"):
         raise ValueError("order must be 'F' or 'C'")
     if orthogonalizer not in ("auto", "eigh", "cholesky"):
@@ -500,11 +546,12 @@ def localmd_decomposition(
         a_f = int(temporal_avg_factor)
         if n_loc > 0 and n_win == 1:
             ws = ctx.workspace(lib.pmd_tiles_workspace_bytes(n_loc, b1, b2, P_pool, r, a_f, crop, ldv, Dl))
-            ctx.call("pmd_tiles_decompose", ptr(xf), ld_f, Dl, crop, ptr(pix_loc_dev), n_loc, b1, b2, ptr(pool_q_dev),
-                     pool_q.shape[1], P_pool, ptr(pool_idx_dev), ptr(pool_w_dev), r, a_f, thr_s32, thr_t32,
-                     int(max_consecutive_failures), seed, t_lo, 1, ptr(ut_dev[t_lo:]), ptr(v_dev[t_lo:]), ldv,
-                     ptr(stats_dev[t_lo:]), ptr(good_dev[t_lo:]), ptr(keep_dev[t_lo:]), ptr(ranks_dev[t_lo:]),
-                     ptr(lam_dev[t_lo:]), ptr(ws), ws.numel())
+            _tiles_decompose(ctx, (ptr(xf), ld_f, Dl, crop, ptr(pix_loc_dev), n_loc, b1, b2, ptr(pool_q_dev),
+                                   pool_q.shape[1], P_pool, ptr(pool_idx_dev), ptr(pool_w_dev), r, a_f, thr_s32, thr_t32,
+                                   int(max_consecutive_failures), seed, t_lo, 1, ptr(ut_dev[t_lo:]), ptr(v_dev[t_lo:]), ldv,
+                                   ptr(stats_dev[t_lo:]), ptr(good_dev[t_lo:]), ptr(keep_dev[t_lo:]), ptr(ranks_dev[t_lo:]),
+                                   ptr(lam_dev[t_lo:])), ws, (n_loc, b1, b2, P_pool, r, a_f, crop, ldv, Dl, dpad),
+                             temporal_denoiser, spatial_denoiser)
         elif n_loc > 0:
             # several windows: first window = single_block_md, later ones fit the residual (decomposition.py:471-515);
             # the Gaussian matrix of (tile, window) is logical array tile * n_win + window
@@ -518,11 +565,14 @@ def localmd_decomposition(
                 xw[:Dl, :win_len] = xf[:Dl, w0:w0 + win_len]
                 if widx == 0:
                     ws = ctx.workspace(lib.pmd_tiles_workspace_bytes(n_loc, b1, b2, P_pool, r, a_f, win_len, ld_w, Dl))
-                    ctx.call("pmd_tiles_decompose", ptr(xw), ld_w, Dl, win_len, ptr(pix_loc_dev), n_loc, b1, b2,
-                             ptr(pool_q_dev), pool_q.shape[1], P_pool, ptr(pool_idx_dev), ptr(pool_w_dev), r, a_f, thr_s32,
-                             thr_t32, int(max_consecutive_failures), seed, t_lo * n_win, n_win, ptr(ut_dev[t_lo:]), ptr(vw),
-                             ld_w, ptr(stats_dev[t_lo:]), ptr(good_dev[t_lo:]), ptr(keep_dev[t_lo:]), ptr(ranks_dev[t_lo:]),
-                             ptr(lam_dev[t_lo:]), ptr(ws), ws.numel())
+                    # the denoiser hooks act in single_block_md only, i.e. in the first window (decomposition.py:476-488)
+                    _tiles_decompose(ctx, (ptr(xw), ld_w, Dl, win_len, ptr(pix_loc_dev), n_loc, b1, b2,
+                                           ptr(pool_q_dev), pool_q.shape[1], P_pool, ptr(pool_idx_dev), ptr(pool_w_dev), r, a_f,
+                                           thr_s32, thr_t32, int(max_consecutive_failures), seed, t_lo * n_win, n_win,
+                                           ptr(ut_dev[t_lo:]), ptr(vw), ld_w, ptr(stats_dev[t_lo:]), ptr(good_dev[t_lo:]),
+                                           ptr(keep_dev[t_lo:]), ptr(ranks_dev[t_lo:]), ptr(lam_dev[t_lo:])), ws,
+                                     (n_loc, b1, b2, P_pool, r, a_f, win_len, ld_w, Dl, dpad), temporal_denoiser,
+                                     spatial_denoiser)
                     ctx.call("pmd_tiles_truncate", ptr(ut_dev[t_lo:]), dpad, ptr(ranks_dev[t_lo:]), n_loc)
                 else:
                     ws = ctx.workspace(lib.pmd_tiles_residual_workspace_bytes(n_loc, b1, b2, r, a_f, win_len, Dl))

@@ -454,3 +454,89 @@ def test_full_pipeline_long_time_axis(gpu_ctx):
     mov = _movie(5000, 40, 40, seed=11)
     pmd, diag, ref = _compare_full(gpu_ctx, mov, (20, 20), 5000, max_components=8, background_rank=3, sim_iters=8)
     _check_full(pmd, diag, ref, mov, vt_tol=3e-3)
+
+
+def _smooth_time(v):
+    """(traces, frames) -> same shape; works on numpy arrays (oracle) and torch device tensors (HIP path)."""
+    out = v * 1.0
+    out[:, 1:-1] = 0.25 * v[:, :-2] + 0.5 * v[:, 1:-1] + 0.25 * v[:, 2:]
+    return out
+
+
+def _smooth_space(s):
+    """(components, b1, b2) -> same shape: 5-point smoothing of the interior."""
+    out = s * 1.0
+    out[:, 1:-1, 1:-1] = 0.5 * s[:, 1:-1, 1:-1] + 0.125 * (s[:, :-2, 1:-1] + s[:, 2:, 1:-1] + s[:, 1:-1, :-2] + s[:, 1:-1, 2:])
+    return out
+
+
+@pytest.mark.parametrize("which", ["temporal", "spatial", "both"])
+def test_full_pipeline_denoiser_hooks(gpu_ctx, which):
+    """spatial_denoiser / temporal_denoiser of single_block_md (decomposition.py:300, :304-313).  The hooks are
+    linear here, so the result does not depend on the sign / rotation conventions of the intermediate bases."""
+    mov = _movie(600, 40, 50, seed=21)
+    kw = dict(max_components=6, background_rank=2, sim_iters=10)
+    if which in ("temporal", "both"):
+        kw["temporal_denoiser"] = _smooth_time
+    if which in ("spatial", "both"):
+        kw["spatial_denoiser"] = _smooth_space
+    pmd, diag, ref = _compare_full(gpu_ctx, mov, (20, 20), 600, **kw)
+    _check_full(pmd, diag, ref, mov, vt_tol=3e-3)
+    # the hook changes the answer (guards against a silently ignored argument)
+    plain, _, _ = _compare_full(gpu_ctx, mov, (20, 20), 600, max_components=6, background_rank=2, sim_iters=10)
+    assert plain.u.shape != pmd.u.shape or not np.allclose(plain.u.data, pmd.u.data, rtol=1e-4, atol=1e-6)
+
+
+def test_denoiser_hooks_batched_and_first_window_only(gpu_ctx):
+    """A callable marked ``batched`` sees all tiles at once and gives the same result as the per-tile calls; with
+    several temporal windows the hooks act in the first window only (decomposition.py:476-488)."""
+    import localmd_amd
+    from localmd_amd import decomposition as Dm
+
+    Dm.QUIET = True
+    mov = _movie(800, 40, 40, seed=22)
+    calls = {"t": 0, "s": 0}
+
+    def t_one(v):
+        calls["t"] += 1
+        assert v.ndim == 2 and v.shape == (5, 400) and v.is_cuda
+        return torch_tanh(v)
+
+    def s_one(s):
+        calls["s"] += 1
+        assert s.shape == (5, 20, 20) and s.is_cuda
+        return _smooth_space(s)
+
+    def torch_tanh(v):
+        import torch
+
+        sc = v.abs().amax(dim=-1, keepdim=True) + 1e-6
+        return torch.tanh(2.0 * v / sc) * sc
+
+    def t_all(v):
+        assert v.ndim == 3 and v.shape[1:] == (5, 400)
+        return torch_tanh(v)
+
+    t_all.batched = True
+
+    def s_all(s):
+        assert s.ndim == 4 and s.shape[1:] == (5, 20, 20)
+        out = s * 1.0
+        out[:, :, 1:-1, 1:-1] = 0.5 * s[:, :, 1:-1, 1:-1] + 0.125 * (s[:, :, :-2, 1:-1] + s[:, :, 2:, 1:-1] +
+                                                                      s[:, :, 1:-1, :-2] + s[:, :, 1:-1, 2:])
+        return out
+
+    s_all.batched = True
+    kw = dict(max_components=5, background_rank=2, window_chunks=400, seed=5, thresholds=(1.0, 1.0), ctx=gpu_ctx)
+    np.random.seed(3)
+    a = localmd_amd.localmd_decomposition(mov, (20, 20), 800, temporal_denoiser=t_one, spatial_denoiser=s_one, **kw)
+    assert calls == {"t": 9, "s": 9}  # 3 x 3 tiles, first window only
+    np.random.seed(3)
+    b = localmd_amd.localmd_decomposition(mov, (20, 20), 800, temporal_denoiser=t_all, spatial_denoiser=s_all, **kw)
+    np.testing.assert_array_equal(a.u.indices, b.u.indices)
+    np.testing.assert_array_equal(a.u.data, b.u.data)
+    np.testing.assert_array_equal(a.s, b.s)
+    with pytest.raises(ValueError):
+        localmd_amd.localmd_decomposition(mov, (20, 20), 800, temporal_denoiser=lambda v: v[:, :-1], **kw)
+    with pytest.raises(TypeError):
+        localmd_amd.localmd_decomposition(mov, (20, 20), 800, spatial_denoiser="median", **kw)
