@@ -206,6 +206,15 @@ int pmd_csr_fill(pmd_ctx* ctx, int d1, int d2, int order_f, int b1, const int* c
 int pmd_gemm(pmd_ctx* ctx, int transA, int transB, int m, int n, int k, float alpha, const float* A, long lda,
              const float* B, long ldb, float beta, float* C, long ldc);
 
+/* A18: expansion back into pixels (pmdarray.py:132-171, PMDArray.__getitem__: spatial.dot(temporal), times the
+ * noise image, plus the mean image, frames first).  pmd_csr_rows_spmm: out[p][f] = sum over the nonzeros i of CSR
+ * row rows[p] (rows == NULL: row p) of data[i] * B[indices[i]][f], f < ncols; B is the dense (R diag(s)) Vt[:, frames]
+ * or R diag(s).  pmd_transpose_affine: dst[c][r] = src[r][c] * scale[r] + shift[r] (scale / shift may be NULL). */
+int pmd_csr_rows_spmm(pmd_ctx* ctx, const int64_t* indptr, const int* indices, const float* data, const int* rows, long n_sel,
+                      const float* B, long ldb, int ncols, float* out, long ldo);
+int pmd_transpose_affine(pmd_ctx* ctx, const float* src, long lds_, long rows, int cols, const float* scale,
+                         const float* shift, float* dst, long ldd);
+
 /* ---- kernel-level entry points (used by the parity tests; same kernels as above) ---------- */
 int pmdk_tile_atx(pmd_ctx* ctx, const float* X, long ldx, const int* pix, int pix_stride, long row0_stride, int d,
                   const float* A, long a_tile_stride, int a_ld, float* Out, long out_tile_stride, long ldo, int n_tiles,

@@ -43,6 +43,8 @@ SIGNATURES = {
                                   c_i, c_u64, c_u32, c_u32, c_p, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_sz]),
     "pmd_tiles_decompose_staged": (c_i, [c_p, c_p, c_l, c_l, c_i, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_f,
                                          c_f, c_i, c_u64, c_u32, c_u32, c_p, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_i]),
+    "pmd_csr_rows_spmm": (c_i, [c_p, c_p, c_p, c_p, c_p, c_l, c_p, c_l, c_i, c_p, c_l]),
+    "pmd_transpose_affine": (c_i, [c_p, c_p, c_l, c_l, c_i, c_p, c_p, c_p, c_l]),
     "pmd_tiles_hook_offsets": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_l, c_l, c_p, c_p]),
     "pmd_tiles_residual_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i, c_i, c_l]),
     "pmd_tiles_residual": (c_i, [c_p, c_p, c_l, c_l, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_u64, c_u32, c_u32,

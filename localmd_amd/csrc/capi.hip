@@ -255,6 +255,19 @@ int pmd_gemm(pmd_ctx* ctx, int transA, int transB, int m, int n, int k, float al
   return pmd_gemm_rm(ctx, transA, transB, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc);
 }
 
+int pmd_csr_rows_spmm(pmd_ctx* ctx, const int64_t* indptr, const int* indices, const float* data, const int* rows, long n_sel,
+                      const float* B, long ldb, int ncols, float* out, long ldo) {
+  CTX_CHECK(ctx);
+  if (!indptr || !indices || !data || !B || !out) return pmd_fail(ctx, PMD_ERR_ARG, "pmd_csr_rows_spmm", "null pointer");
+  return pmd_csr_rows_spmm_impl(ctx, (const long*)indptr, indices, data, rows, n_sel, B, ldb, ncols, out, ldo);
+}
+int pmd_transpose_affine(pmd_ctx* ctx, const float* src, long lds_, long rows, int cols, const float* scale,
+                         const float* shift, float* dst, long ldd) {
+  CTX_CHECK(ctx);
+  if (!src || !dst) return pmd_fail(ctx, PMD_ERR_ARG, "pmd_transpose_affine", "null pointer");
+  return pmd_transpose_affine_impl(ctx, src, lds_, rows, cols, scale, shift, dst, ldd);
+}
+
 int pmd_gram_blocks(pmd_ctx* ctx, const float* Uw, int dpad, int b1, int b2, const int* tile_pix, const int* pairs,
                     int n_pairs, const int* origins, const int* col_off, const int* ranks, int n_tiles, int Rt,
                     const float* basis, long D, int K, float* Gblk, float* Gbg, float* Gstrip, long ldgs) {

@@ -54,6 +54,12 @@ int pmd_launch_stats_roughness(pmd_ctx* ctx, const float* Ut, long u_tile_stride
 int pmd_launch_decide(pmd_ctx* ctx, const float* stats, int r, float thr_s, float thr_t, int max_fail, int cap,
                       int n_tiles, int* good, int* keep, int* ranks);
 
+// expand.hip
+int pmd_csr_rows_spmm_impl(pmd_ctx* ctx, const long* indptr, const int* indices, const float* data, const int* rows,
+                           long n_sel, const float* B, long ldb, int ncols, float* out, long ldo);
+int pmd_transpose_affine_impl(pmd_ctx* ctx, const float* src, long lds_, long rows, int cols, const float* scale,
+                              const float* shift, float* dst, long ldd);
+
 // pipeline.hip
 size_t pmd_tiles_workspace_bytes_impl(int n, int d, int P, int r, int a, int t_crop, long ldv, long n_rows);
 int pmd_tiles_decompose_impl(pmd_ctx* ctx, const float* Xf, long ldx, long n_rows, int t_crop, const int* tile_pix, int n, int b1,

@@ -73,8 +73,12 @@ def _check_properties(pmd, diag, noisy, T, d1, d2, block):
     pi = rng.integers(0, d1, 300)
     pj = rng.integers(0, d2, 300)
     err_rec, err_in = [], []
-    for a, b in zip(pi[:40], pj[:40]):
-        trace = pmd[:, int(a), int(b)]
+    # traces through the device expansion (PMDArray.to_device): the host form would build the (R x T) matrix
+    pmd.to_device(device=noisy.device.index)
+    traces = pmd[:, [int(a) for a in pi[:40]], [int(b) for b in pj[:40]]]  # pairwise fancy indexing: (T, 40)
+    pmd.to_host()
+    for q, (a, b) in enumerate(zip(pi[:40], pj[:40])):
+        trace = traces[:, q]
         c = clean[:, a, b].cpu().numpy()
         y = noisy[:, a, b].cpu().numpy()
         err_rec.append(np.mean((trace - c) ** 2))

@@ -540,3 +540,33 @@ def test_denoiser_hooks_batched_and_first_window_only(gpu_ctx):
         localmd_amd.localmd_decomposition(mov, (20, 20), 800, temporal_denoiser=lambda v: v[:, :-1], **kw)
     with pytest.raises(TypeError):
         localmd_amd.localmd_decomposition(mov, (20, 20), 800, spatial_denoiser="median", **kw)
+
+
+def test_pmdarray_device_expansion_matches_host(gpu_ctx):
+    """PMDArray.to_device(): __getitem__ on the GPU returns what the reference's SciPy / NumPy expansion
+    (pmdarray.py:132-171) returns, for every kind of key."""
+    import localmd_amd
+    from localmd_amd import decomposition as Dm
+
+    Dm.QUIET = True
+    mov = _movie(600, 40, 50, seed=31)
+    np.random.seed(1)
+    pmd = localmd_amd.localmd_decomposition(mov, (20, 20), 600, max_components=6, background_rank=2, seed=9, sim_iters=8,
+                                            ctx=gpu_ctx)
+    keys = [
+        (slice(None),), (5,), (slice(10, 300, 7),), ([3, 1, 599, 1],), (slice(0, 64), slice(4, 30), slice(7, 50)),
+        (slice(None), 7, 9), (17, slice(None), slice(None)), (slice(100, 420), [1, 5, 9], [2, 2, 40]),
+        (np.array([0, 7, 8]), slice(0, 40, 3), 11), (slice(0, 5), 3), (slice(None), slice(None), slice(None)),
+        (slice(2, 2), slice(None), slice(None)),
+    ]
+    host = [pmd[k if len(k) > 1 else k[0]] for k in keys]
+    pmd.to_device(ctx=gpu_ctx)
+    try:
+        for k, h in zip(keys, host):
+            g = pmd[k if len(k) > 1 else k[0]]
+            assert g.shape == h.shape and g.dtype == h.dtype == np.float32, (k, g.shape, h.shape)
+            np.testing.assert_allclose(g, h, rtol=2e-5, atol=2e-5 * max(1.0, float(np.abs(h).max()) if h.size else 1.0))
+    finally:
+        pmd.to_host()
+    assert pmd._dev is None
+    np.testing.assert_array_equal(pmd[5], host[1])

@@ -276,3 +276,20 @@ def test_product_never_imports_the_oracle():
         if fn.endswith(".py"):
             src = open(os.path.join(pkg, fn)).read()
             assert "oracle" not in src.replace("the oracle", "").replace("oracle/", ""), fn
+
+
+def test_pmdarray_to_device_needs_a_gpu():
+    """No CPU stand-in for the device expansion: without a HIP device to_device() raises."""
+    import torch
+    import scipy.sparse
+    from localmd_amd.pmdarray import PMDArray
+    from localmd_amd._lib import PMDLibraryError
+
+    if torch.cuda.is_available():
+        pytest.skip("a HIP device is present")
+    u = scipy.sparse.coo_matrix(np.eye(6, 3))
+    arr = PMDArray(u, np.eye(3, dtype=np.float32), np.ones(3, np.float32), np.ones((3, 4), np.float32), (4, 2, 3), "F",
+                   np.zeros((2, 3), np.float32), np.ones((2, 3), np.float32))
+    with pytest.raises(PMDLibraryError):
+        arr.to_device()
+    assert arr[0].shape == (2, 3)
