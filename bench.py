@@ -188,6 +188,17 @@ def main():
             "avg_launch_ms": avg_sv_ms, "launches_timed": sv_n, "launches_per_step": n_eig - 1,
             "algorithmic_mb_per_launch": avg_bytes / 1e6, "matrix_order": n_eig,
         }
+        # fabric-side traffic of the same launches from the committed PMC pass (profiles/r01_pmc_sytrd_n10000.json:
+        # separate rocprofv3 --pmc FETCH_SIZE run over one n = 10^4 tridiagonalisation, gfx950 x2 correction applied,
+        # mean over the launches j = 32, 96, ... that are timed here); only valid for a matrix of that order
+        try:
+            pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_sytrd_n10000.json")))
+            if abs(n_eig - pmc["matrix_order"]) <= 1:
+                roofline["traffic"] = pmc["traffic_bytes_per_launch_sample_mean"] / 1e9
+                roofline["traffic_unit"] = "GB per launch (L2 -> fabric reads, Infinity Cache hits included)"
+                roofline["traffic_over_algorithmic"] = pmc["traffic_over_algorithmic_sample"]
+        except (OSError, KeyError, ValueError):
+            pass
     out = {
         "metric": "frames/sec PMD decomposition", "value": value, "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
