@@ -474,3 +474,41 @@ def test_sytrd_beyond_one_batch_of_partials(gpu_ctx):
     assert np.abs(ev1 - ev0).max() < 2e-5 * np.abs(ev0).max()
     assert abs(d1.sum() - d0.sum()) < 1e-5 * abs(d0.sum())   # trace is invariant
     np.testing.assert_allclose(d1[:50], d0[:50], rtol=1e-4)   # the first columns have not drifted yet
+
+
+def test_sytrd_persistent_symv_is_bit_identical(gpu_ctx, monkeypatch):
+    """The persistent forms of the symv (opt-in, PMD_SYMV_PERSIST=N: register double-buffered, or single-buffered
+    with PMD_SYMV_PERSIST_DB=0) share tile numbering and every summation order with the default one-tile-per-
+    workgroup form: same d, e, tau and reflectors, bit for bit, for any number of persistent workgroups."""
+    torch = _t()
+    ctx = gpu_ctx
+    n = 7003
+    g = torch.Generator(device=ctx.device).manual_seed(9)
+    X = torch.randn((n, n + 300), device=ctx.device, generator=g)
+    S = (X @ X.T) / n
+    del X
+    ld = (n + 3) // 4 * 4
+    Sp = torch.zeros((n, ld), device=ctx.device)
+    Sp[:, :n] = S
+    del S
+
+    def run(mode, db="1"):
+        if mode is None:
+            monkeypatch.delenv("PMD_SYMV_PERSIST", raising=False)
+        else:
+            monkeypatch.setenv("PMD_SYMV_PERSIST", mode)
+        monkeypatch.setenv("PMD_SYMV_PERSIST_DB", db)
+        A = Sp.clone()
+        d = torch.zeros(n, device=ctx.device)
+        e = torch.zeros(n, device=ctx.device)
+        tau = torch.zeros(n, device=ctx.device)
+        ctx.call("pmdk_sytrd", n, P(A), ld, P(d), P(e), P(tau), 1)
+        ctx.sync()
+        return A.cpu().numpy(), d.cpu().numpy(), e.cpu().numpy(), tau.cpu().numpy()
+
+    ref = run(None)  # default: one tile per workgroup
+    assert np.all(np.isfinite(ref[1])) and np.all(np.isfinite(ref[2]))
+    for mode, db in (("256", "1"), ("97", "1"), ("300", "1"), ("512", "0"), ("131", "0")):
+        out = run(mode, db)
+        for a, b in zip(out, ref):
+            np.testing.assert_array_equal(a, b)
