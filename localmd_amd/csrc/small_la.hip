@@ -171,12 +171,21 @@ __global__ __launch_bounds__(EIG_THREADS) void small_eig_kernel(const double* __
         double c = 1.0, s = 0.0;
         if (q < n) {
           const double app = A[p * EIG_LD + p], aqq = A[q * EIG_LD + q], apq = A[p * EIG_LD + q];
-          if (fabs(apq) > 1e-17 * sqrt(fabs(app * aqq)) && fabs(apq) > 1e-300) {
-            const double th = (aqq - app) / (2.0 * apq);
-            const double t = ((th >= 0.0) ? 1.0 : -1.0) / (fabs(th) + sqrt(1.0 + th * th));
-            c = 1.0 / sqrt(1.0 + t * t);
+          const double prod = fabs(app * aqq), apq2 = apq * apq;
+          if (apq2 > 1e-34 * prod && fabs(apq) > 1e-300) {
+            // This chain sits between two barriers of every step, so it is kept short: t = tan(theta) from fp32
+            // arithmetic on exponent-normalised operands (an error of 1e-7 in t leaves 1e-7 apq behind instead of
+            // zero - the next sweep takes it; convergence stays quadratic), then c = 1/sqrt(1 + t^2), s = t c in
+            // fp64, which is what keeps the accumulated rotations orthogonal to fp64 accuracy.
+            const double num = aqq - app, den = 2.0 * apq;
+            const int ex = max(__builtin_amdgcn_frexp_exp(num), __builtin_amdgcn_frexp_exp(den));
+            const float th = (float)ldexp(num, -ex) / (float)ldexp(den, -ex);
+            const float ath = fabsf(th);
+            const float t32 = (ath > 1e9f) ? 0.5f / th : copysignf(1.0f, th) / (ath + sqrtf(1.0f + th * th));
+            const double t = (double)t32;
+            c = rsqrt(1.0 + t * t);
             s = t * c;
-            if (fabs(apq) > 1e-12 * sqrt(fabs(app * aqq))) flag[0] = 1;
+            if (apq2 > 1e-24 * prod) flag[0] = 1;
           }
         }
         cs[2 * tid] = c; cs[2 * tid + 1] = s;
