@@ -51,6 +51,7 @@ struct sytrd_bufs {
   double* NP;   // per advance workgroup: partial sum of squares
   float* scal;  // beta, tau, scale of the current reflector
   int cw;       // tile width (positions) of the symv launch whose partials RP / CP / SP currently hold
+  int delay;    // start offset of the second workgroup of every CU in the symv, units of 1024 cycles
 };
 
 __device__ __forceinline__ int tile_r0(int cs, int b) { return (cs + b * BR) & ~3; }
@@ -98,6 +99,43 @@ __device__ __forceinline__ float batch_sum(const float* __restrict__ p, long str
   return acc;
 }
 
+// batch_sum in two halves, so that the first batches of several sums can be issued back to back before anything
+// waits (a sum's continuation loop is control flow: loads that follow it in program order would otherwise start
+// one memory round trip later).  batch_finish adds in exactly the order of batch_sum.
+// (addresses: wave-uniform base pointer + 32-bit byte offset per lane - one add, one compare and one select per load
+// instead of a 64-bit multiply-add: with ~130 loads per thread the address arithmetic was most of this kernel)
+template <int U>
+__device__ __forceinline__ void batch_issue(const float* __restrict__ base, unsigned elem_off, unsigned stride, int first, int step,
+                                            int count, float* t) {
+  const char* bp = reinterpret_cast<const char*>(base);
+  const unsigned off0 = elem_off * 4u;                              // idx = 0 (always valid to read)
+  const unsigned offf = off0 + (unsigned)first * stride * 4u;       // idx = first
+  const unsigned inc = (unsigned)step * stride * 4u;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const unsigned off = (first + u * step < count) ? offf + (unsigned)u * inc : off0;
+    t[u] = *reinterpret_cast<const float*>(bp + off);
+  }
+}
+template <int U>
+__device__ __forceinline__ float batch_finish(const float* __restrict__ p, long stride, int first, int step, int count,
+                                              const float* t0) {
+  float acc = 0.f;
+#pragma unroll
+  for (int u = 0; u < U; ++u) acc += (first + u * step < count) ? t0[u] : 0.f;
+  for (int base = first + U * step; base < count; base += U * step) {
+    float t[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int idx = base + u * step;
+      t[u] = p[(long)((idx < count) ? idx : 0) * stride];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc += (base + u * step < count) ? t[u] : 0.f;
+  }
+  return acc;
+}
+
 // ------------------------------------------------------------------------------------------
 // FIN: finish w of column jp = j - 1 (slatrd steps after the symv):
 //        w_pre = A v - V (W^T v) - W (V^T v);  w = tau w_pre - (tau^2/2)(w_pre^T v) v
@@ -109,6 +147,26 @@ __device__ __forceinline__ float batch_sum(const float* __restrict__ p, long str
 // comes out bit-identical to what the owner of that position stores.
 // ------------------------------------------------------------------------------------------
 constexpr int APOS = 64;
+
+#ifdef PMD_SYMV_TRACE
+// Debug build only (PMD_EXTRA_FLAGS=-DPMD_SYMV_TRACE): wall-clock stamps (100 MHz) of the phases of every workgroup
+// of the symv launch of column PMD_SYMV_TRACE_J, read back with pmdk_symv_trace (scripts/symv_trace.py).
+#define PMD_SYMV_TRACE_J 32
+__device__ unsigned long long g_symv_trace[4096 * 8];
+#define TRACE_STAMP(slot)                                                                     \
+  do {                                                                                        \
+    if (j == PMD_SYMV_TRACE_J && threadIdx.x == 0 && wg < 4096) g_symv_trace[wg * 8 + (slot)] = wall_clock64(); \
+  } while (0)
+__device__ unsigned long long g_adv_trace[1024 * 8];
+#define ADV_STAMP(slot)                                                                       \
+  do {                                                                                        \
+    if (FIN && UPD && j == PMD_SYMV_TRACE_J && threadIdx.x == 0 && blockIdx.x < 1024) g_adv_trace[blockIdx.x * 8 + (slot)] = wall_clock64(); \
+  } while (0)
+#else
+#define TRACE_STAMP(slot) do {} while (0)
+#define ADV_STAMP(slot) do {} while (0)
+#endif
+
 
 template <bool FIN, bool UPD>
 __global__ __launch_bounds__(320) void sytrd_advance_kernel(float* __restrict__ A, long ld, int n, int j, int j0,
@@ -135,46 +193,63 @@ __global__ __launch_bounds__(320) void sytrd_advance_kernel(float* __restrict__ 
   float vkv[16], wkv[16];
   // every load below is unconditional (clamped index + select): the compiler turns a guarded load into a
   // branch with a full wait behind it, which serialises the ~80 independent loads of a thread
+  ADV_STAMP(0);
   const float xj = A[(long)j * ld + r];
   if (FIN) {
+    // every load of this phase is issued here, back to back, before anything is summed
+    const int cs = j;  // first row of the symv launch of column jp
+    const int nbk = (n - cs + BR - 1) / BR;
+    const int bc = (r - cs) / BR;
+    const int nq = tile_nq(n, cs, bc, B.cw);
+    int bmax = bc;
+    if (bc + 1 < nbk && tile_r0(cs, bc + 1) <= r) bmax = bc + 1;
+    const int ndch = (n - j + DCH - 1) / DCH;  // dot chunks of the symv launch of column jp (cs = j)
+    const int kd = tid & (NB - 1), whichd = (tid >> 6) & 1;
+    const int kcd = (kd < ip) ? kd : 0;
+    const float* dp = B.DP + (long)whichd * NB + kcd;
+    float t_rp[10], t_cp[40], t_dp[40], t_sp[4];
+    batch_issue<10>(B.RP, (unsigned)r, (unsigned)B.ldp, part, 4, nq, t_rp);
+    batch_issue<40>(B.CP, (unsigned)r, (unsigned)B.ldp, part, 4, bmax + 1, t_cp);
+    xv = A[(long)jp * ld + r];
     {
-      const int cs = j;  // first row of the symv launch of column jp
-      const int nbk = (n - cs + BR - 1) / BR;
-      const int bc = (r - cs) / BR;
-      const int nq = tile_nq(n, cs, bc, B.cw);
-      int bmax = bc;
-      if (bc + 1 < nbk && tile_r0(cs, bc + 1) <= r) bmax = bc + 1;
-      ypart = batch_sum<10>(B.RP + r, B.ldp, part, 4, nq) + batch_sum<40>(B.CP + r, B.ldp, part, 4, bmax + 1);
-      xv = A[(long)jp * ld + r];
+      const char* vb = reinterpret_cast<const char*>(A + (long)j0 * ld);  // panel rows: uniform base + small offsets
+      const char* wb = reinterpret_cast<const char*>(B.W);
+      const unsigned r4 = (unsigned)r * 4u, ldb = (unsigned)ld * 4u, ldwb = (unsigned)B.ldw * 4u;
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
         const int k = part + 4 * t;
-        const int kc = (k < ip) ? k : 0;
-        vkv[t] = A[(long)(j0 + kc) * ld + r];
-        wkv[t] = B.W[(long)kc * B.ldw + r];
+        const unsigned kc = (k < ip) ? (unsigned)k : 0u;
+        vkv[t] = *reinterpret_cast<const float*>(vb + (kc * ldb + r4));
+        wkv[t] = *reinterpret_cast<const float*>(wb + (kc * ldwb + r4));
       }
     }
+    batch_issue<40>(B.DP, (unsigned)(whichd * NB + kcd), 2u * NB, 0, 1, ndch, t_dp);
+    const float* sidep = (whichd == 0) ? B.W + (long)kcd * B.ldw + j : A + (long)(j0 + kcd) * ld + j;
+    const float sidev = *sidep;
+    batch_issue<4>(B.SP, 0u, 1u, tid, 320, nsp, t_sp);
     tau = B.scal[1];
     scale = B.scal[2];
-    const int ndch = (n - j + DCH - 1) / DCH;  // dot chunks of the symv launch of column jp (cs = j)
-    if (tid < 2 * NB) {
-      const int k = tid & (NB - 1), which = tid >> 6;
-      const int kc = (k < ip) ? k : 0;
-      float acc = batch_sum<40>(B.DP + (long)which * NB + kc, 2 * NB, 0, 1, ndch);
-      if (k >= ip) acc = 0.f;
-      const float side = UPD ? (which == 0 ? B.W[(long)kc * B.ldw + j] : A[(long)(j0 + kc) * ld + j]) : 0.f;
-      if (which == 0) {
-        s_dW[k] = acc;
-        s_Wj[k] = side;
-      } else {
-        s_dV[k] = acc;
-        s_Vj[k] = side;
+    ADV_STAMP(6);
+    ypart = batch_finish<10>(B.RP + r, B.ldp, part, 4, nq, t_rp) + batch_finish<40>(B.CP + r, B.ldp, part, 4, bmax + 1, t_cp);
+    {
+      float acc = batch_finish<40>(dp, 2 * NB, 0, 1, ndch, t_dp);
+      if (kd >= ip) acc = 0.f;
+      const float side = UPD ? sidev : 0.f;
+      if (tid < NB) {
+        s_dW[kd] = acc;
+        s_Wj[kd] = side;
+      } else if (tid < 2 * NB) {
+        s_dV[kd] = acc;
+        s_Vj[kd] = side;
       }
     }
-    float part_sp = batch_sum<4>(B.SP, 1, tid, 320, nsp);
+    ADV_STAMP(1);
+    float part_sp = batch_finish<4>(B.SP, 1, tid, 320, nsp, t_sp);
+    ADV_STAMP(2);
     for (int o = 32; o > 0; o >>= 1) part_sp += __shfl_xor(part_sp, o);
     if (lane == 0) s_red[wave] = part_sp;
     __syncthreads();
+    ADV_STAMP(3);
     const float vav = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) + s_red[4];
     float cross = 0.f;
     for (int k = 0; k < ip; ++k) cross += s_dV[k] * s_dW[k];
@@ -194,6 +269,7 @@ __global__ __launch_bounds__(320) void sytrd_advance_kernel(float* __restrict__ 
     }
     __syncthreads();
   }
+  ADV_STAMP(4);
   float w = 0.f, v = 0.f, u = 0.f;
   if (FIN && combiner) {
     const float y = (s_y[0][slot] + s_y[1][slot]) + (s_y[2][slot] + s_y[3][slot]);
@@ -222,6 +298,7 @@ __global__ __launch_bounds__(320) void sytrd_advance_kernel(float* __restrict__ 
   }
   for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
   if (lane == 0) B.NP[blockIdx.x] = sq;
+  ADV_STAMP(5);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -231,6 +308,7 @@ __global__ __launch_bounds__(320) void sytrd_advance_kernel(float* __restrict__ 
 //       CP[b][r]  = sum_{c in tile, c <  r} A[c][r] v[c]
 //   dot workgroups: W_k^T v and V_k^T v over 256 positions for the k < j - j0 panel columns.
 // ------------------------------------------------------------------------------------------
+
 template <int CWT>
 __global__ __launch_bounds__(512, CWT == 1024 ? 2 : 4) void sytrd_symv_kernel(const float* __restrict__ A, long ld, int n, int j, int j0,
                                                          sytrd_bufs B, int n_np, int npairs, int nbk,
@@ -239,6 +317,12 @@ __global__ __launch_bounds__(512, CWT == 1024 ? 2 : 4) void sytrd_symv_kernel(co
   constexpr int NRG = 8 / NPG;     // row groups
   constexpr int RPW = BR / NRG;    // rows per wave: 32 or 16, all in flight at once
   constexpr int LOGR = (RPW == 32) ? 5 : (RPW == 16) ? 4 : 3;
+#ifdef PMD_SYMV_TRACE
+  if (j == PMD_SYMV_TRACE_J && threadIdx.x == 0) {
+    const int wg_ = blockIdx.y * gridDim.x + blockIdx.x;
+    if (wg_ < 4096) g_symv_trace[wg_ * 8 + 6] = wall_clock64();
+  }
+#endif
   __shared__ float s_v[BR];
   __shared__ float s_row[NPG][BR];
   __shared__ float s_col[NPG][NRG - 1][64][4];
@@ -250,6 +334,13 @@ __global__ __launch_bounds__(512, CWT == 1024 ? 2 : 4) void sytrd_symv_kernel(co
   const float* xr = A + (long)j * ld;
   const int wg = blockIdx.y * gridDim.x + blockIdx.x;
   const bool is_dot = (int)blockIdx.y >= npairs;
+  TRACE_STAMP(0);
+  // The workgroups of the first round start together and then stay in lockstep (trace: scripts/symv_trace.py):
+  // the two workgroups of a CU load at the same time and reduce at the same time, and the memory pipe idles
+  // 30 % of the launch.  The second workgroup of every CU (ids 256..511: the dispatcher fills every CU once
+  // before it fills a second slot) therefore starts half a period late.
+  if (wg >= 256 && wg < 512)
+    for (int w = 0; w < B.delay; ++w) __builtin_amdgcn_s_sleep(16);
 
   // ---- which tile: row blocks are paired (p, nbk-1-p) so that every grid row has about the same work
   int b = blockIdx.y, q = blockIdx.x;
@@ -276,6 +367,19 @@ __global__ __launch_bounds__(512, CWT == 1024 ? 2 : 4) void sytrd_symv_kernel(co
   // Every load of the tile is issued before anything waits: one memory round trip per workgroup.  The
   // loads are unconditional (clamped row / position, results masked later): a guarded load becomes a
   // branch with a full wait behind it.  Rows >= rows repeat the last row and meet v = 0.
+  // wave 0 first asks for the partial norms and the pivot of the reflector (written by the previous launch): its
+  // scalar chain then runs while the tile streams in, instead of starting one round trip after the tile arrived
+  double np_pre[3] = {0.0, 0.0, 0.0};
+  float a0_pre = 0.f;
+  if (wave == 0) {
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int t = lane + 64 * u;
+      np_pre[u] = B.NP[(t < n_np) ? t : 0];
+    }
+    a0_pre = xr[cs];
+  }
+  TRACE_STAMP(7);
   float4 a[RPW];
   float v4[4];
   {
@@ -297,12 +401,15 @@ __global__ __launch_bounds__(512, CWT == 1024 ? 2 : 4) void sytrd_symv_kernel(co
       s_v[tid] = in ? xc : 0.f;
     }
   }
+  TRACE_STAMP(1);
   if (wave == 0) {
     // reflector scalars: fixed-order tree over the partial norms, every lane of wave 0 holds the result
     double xn = 0.0;
-    for (int t = lane; t < n_np; t += 64) xn += B.NP[t];
+#pragma unroll
+    for (int u = 0; u < 3; ++u) xn += (lane + 64 * u < n_np) ? np_pre[u] : 0.0;
+    for (int t = lane + 192; t < n_np; t += 64) xn += B.NP[t];
     for (int o = 32; o > 0; o >>= 1) xn += __shfl_xor(xn, o);
-    const float a0 = xr[cs];
+    const float a0 = a0_pre;
     float beta = a0, tau = 0.f, scale = 0.f;
     if (xn > 0.0) {
       const double nr = sqrt((double)a0 * (double)a0 + xn);
@@ -325,6 +432,7 @@ __global__ __launch_bounds__(512, CWT == 1024 ? 2 : 4) void sytrd_symv_kernel(co
     }
   }
   __syncthreads();
+  TRACE_STAMP(2);
   const float scale = s_sc[2];
 
   if (is_dot) {
@@ -394,6 +502,10 @@ __global__ __launch_bounds__(512, CWT == 1024 ? 2 : 4) void sytrd_symv_kernel(co
       col[3] += a[uu].w * vc;
     }
   }
+#ifdef PMD_SYMV_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  TRACE_STAMP(3);
   // RPW row sums across the 64 lanes: halve the number of values per lane at every exchange; after LOGR
   // exchanges a lane holds one row (index = its top LOGR lane bits), the remaining lane bits are plain adds
 #pragma unroll
@@ -415,6 +527,7 @@ __global__ __launch_bounds__(512, CWT == 1024 ? 2 : 4) void sytrd_symv_kernel(co
     for (int t = 0; t < 4; ++t) s_col[wc][rh - 1][lane][t] = col[t];
   }
   __syncthreads();
+  TRACE_STAMP(4);
   float spart = 0.f;
   if (tid < rows) {
     float rs = s_row[0][tid];
@@ -439,6 +552,7 @@ __global__ __launch_bounds__(512, CWT == 1024 ? 2 : 4) void sytrd_symv_kernel(co
     for (int t = 0; t < 8; ++t) tot += s_red[t];
     B.SP[wg] = tot;
   }
+  TRACE_STAMP(5);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -903,6 +1017,8 @@ int pmd_sytrd_impl(pmd_ctx* ctx, int n, float* A, long lda, float* d, float* e, 
   int cw_fixed = cwf ? atoi(cwf) : 512;
   if (cw_fixed != 256 && cw_fixed != 512 && cw_fixed != 1024) cw_fixed = 512;
   B.cw = CW;
+  const char* dly = getenv("PMD_SYMV_DELAY");
+  B.delay = dly ? atoi(dly) : 0;
   // PMD_SYMV_PERSIST=N: N persistent workgroups for the large trailing blocks (PMD_SYMV_PERSIST_DB=0: single-buffered,
   // two per CU, out of phase).  Off by default: measured at n = 10^4 (scripts/sytrd_ab.py) both forms
   // run a launch at n' ~ 10^4 in 41 us against 43.5 us, lose at n' < 7000 (6 tiles per workgroup: imbalance) and leave
@@ -1046,3 +1162,12 @@ int pmd_syevd(pmd_ctx* ctx, int n, float* A, long lda, float* w, float* work, in
   PMD_LAUNCH_CHECK(ctx, "copy_rows_kernel");
   return PMD_OK;
 }
+
+#ifdef PMD_SYMV_TRACE
+extern "C" int pmdk_adv_trace(unsigned long long* host_out, int count) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_adv_trace), sizeof(unsigned long long) * (size_t)count, 0, hipMemcpyDeviceToHost);
+}
+extern "C" int pmdk_symv_trace(unsigned long long* host_out, int count) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_symv_trace), sizeof(unsigned long long) * (size_t)count, 0, hipMemcpyDeviceToHost);
+}
+#endif

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(512) void read_tiles(const float* __restrict__ A, l
 }
 
 template <int TR, int TC>
-static void run(const float* A, long ld, int n, int cs, float* out) {
+static void run(const float* A, long ld, int n, int cs, float* out, int lds_bytes = 0) {
   std::vector<int2> tiles;
   for (int cb = cs; cb < n; cb += TR) {
     const int r0 = cb & ~3;
@@ -48,15 +48,16 @@ static void run(const float* A, long ld, int n, int cs, float* out) {
   int2* dt; CK(hipMalloc(&dt, tiles.size() * sizeof(int2)));
   CK(hipMemcpy(dt, tiles.data(), tiles.size() * sizeof(int2), hipMemcpyHostToDevice));
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  for (int w = 0; w < 3; ++w) hipLaunchKernelGGL((read_tiles<TR, TC>), dim3(tiles.size()), dim3(512), 0, 0, A, ld, n, cs, dt, out);
+  if (lds_bytes > 65536) CK(hipFuncSetAttribute((const void*)read_tiles<TR, TC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+  for (int w = 0; w < 3; ++w) hipLaunchKernelGGL((read_tiles<TR, TC>), dim3(tiles.size()), dim3(512), lds_bytes, 0, A, ld, n, cs, dt, out);
   const int reps = 20;
   hipEventRecord(e0);
-  for (int w = 0; w < reps; ++w) hipLaunchKernelGGL((read_tiles<TR, TC>), dim3(tiles.size()), dim3(512), 0, 0, A, ld, n, cs, dt, out);
+  for (int w = 0; w < reps; ++w) hipLaunchKernelGGL((read_tiles<TR, TC>), dim3(tiles.size()), dim3(512), lds_bytes, 0, A, ld, n, cs, dt, out);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
   const double np = n - cs;
   const double alg = 4.0 * np * (np + 1) / 2, touched = (double)tiles.size() * TR * TC * 4;
-  printf("n'=%5d tile %3d x %4d: %6zu tiles %7.1f us  algorithmic %.2f TB/s  touched %.2f TB/s\n", n - cs, TR, TC, tiles.size(),
+  printf("lds %6d  n'=%5d tile %3d x %4d: %6zu tiles %7.1f us  algorithmic %.2f TB/s  touched %.2f TB/s\n", lds_bytes, n - cs, TR, TC, tiles.size(),
          ms * 1e3, alg / (ms * 1e-3) / 1e12, touched / (ms * 1e-3) / 1e12);
   CK(hipFree(dt));
 }
@@ -65,15 +66,12 @@ int main() {
   const int n = 10000; const long ld = 10000;
   float* A; CK(hipMalloc(&A, (size_t)n * ld * 4 + 65536)); CK(hipMemset(A, 0, (size_t)n * ld * 4 + 65536));
   float* out; CK(hipMalloc(&out, 1 << 22));
-  for (int cs : {1, 4001, 7001}) {
-    run<64, 512>(A, ld, n, cs, out);
-    run<64, 1024>(A, ld, n, cs, out);
-    run<32, 1024>(A, ld, n, cs, out);
-    run<16, 2048>(A, ld, n, cs, out);
-    run<32, 2048>(A, ld, n, cs, out);
-    run<8, 4096>(A, ld, n, cs, out);
-    run<16, 512>(A, ld, n, cs, out);
-    run<32, 512>(A, ld, n, cs, out);
+  // workgroups per CU limited through the dynamic LDS allocation: 0 -> registers decide (3), 60 KB -> 2, 100 KB -> 1
+  for (int cs : {1, 4001}) {
+    for (int lds : {0, 40 * 1024, 60 * 1024, 100 * 1024}) {
+      run<64, 512>(A, ld, n, cs, out, lds);
+      run<32, 512>(A, ld, n, cs, out, lds);
+    }
   }
   return 0;
 }
