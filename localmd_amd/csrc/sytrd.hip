@@ -302,6 +302,141 @@ __global__ __launch_bounds__(320) void sytrd_advance_kernel(float* __restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------
+// The same step with the loads spread over more SIMDs (phase trace, scripts/symv_trace.py: with 64 positions x
+// 4 parts per workgroup a thread issues ~130 loads and the kernel is bound by instruction issue, 2.8 us before
+// the last load is out).  Here a workgroup owns 32 positions, eight parts sum every eighth partial (waves 0..3,
+// two parts each), wave 4 computes the scalars every position needs (w_jp[j], v^T w) with one partial per lane,
+// waves 5 and 6 sum the panel dot products.  FIN is implied (a previous column exists).  Fixed summation order.
+// ------------------------------------------------------------------------------------------
+constexpr int APOS2 = 32, NPART2 = 8;
+
+__device__ __forceinline__ float wave_tree_sum(float v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+template <bool UPD>
+__global__ __launch_bounds__(448) void sytrd_advance2_kernel(float* __restrict__ A, long ld, int n, int j, int j0,
+                                                             sytrd_bufs B, int nsp, float* __restrict__ d) {
+  __shared__ float s_dW[NB], s_dV[NB], s_Wj[NB], s_Vj[NB];
+  __shared__ float s_y[NPART2][APOS2 + 1], s_u[NPART2][APOS2 + 1];
+  __shared__ float s_red[8];
+  __shared__ float s_bc[2];  // alpha, w_jp[j]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int jp = j - 1;
+  const int ip = jp - j0;  // earlier panel columns seen by column jp
+  const int cs = j;        // first row of the symv launch of column jp
+  const int nbk = (n - cs + BR - 1) / BR;
+  float t_sp[4];
+  batch_issue<4>(B.SP, 0u, 1u, tid, 448, nsp, t_sp);
+  const float tau = B.scal[1], scale = B.scal[2];
+
+  // ---- role-specific loads (wave-uniform branches, straight-line loads inside)
+  const int part = wave * 2 + (lane >> 5), pl = lane & 31;
+  int r = j + blockIdx.x * APOS2 + pl;
+  const bool live = wave < 4 && r < n;
+  if (r >= n) r = n - 1;
+  float t_rp[3], t_cp[20], vkv[8], wkv[8], t_dp[40];
+  float xv = 0.f, xj = 0.f, sidev = 0.f, rp_j = 0.f, cp_j = 0.f;
+  int nq = 0, bmax = 0, nq_j = 0;
+  if (wave < 4) {
+    const int bc = (r - cs) / BR;
+    nq = tile_nq(n, cs, bc, B.cw);
+    bmax = bc;
+    if (bc + 1 < nbk && tile_r0(cs, bc + 1) <= r) bmax = bc + 1;
+    batch_issue<3>(B.RP, (unsigned)r, (unsigned)B.ldp, part, NPART2, nq, t_rp);
+    batch_issue<20>(B.CP, (unsigned)r, (unsigned)B.ldp, part, NPART2, bmax + 1, t_cp);
+    const char* vb = reinterpret_cast<const char*>(A + (long)j0 * ld);
+    const char* wb = reinterpret_cast<const char*>(B.W);
+    const unsigned r4 = (unsigned)r * 4u, ldb = (unsigned)ld * 4u, ldwb = (unsigned)B.ldw * 4u;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int k = part + NPART2 * t;
+      const unsigned kc = (k < ip) ? (unsigned)k : 0u;
+      vkv[t] = *reinterpret_cast<const float*>(vb + (kc * ldb + r4));
+      wkv[t] = *reinterpret_cast<const float*>(wb + (kc * ldwb + r4));
+    }
+    xv = A[(long)jp * ld + r];
+    xj = A[(long)j * ld + r];
+  } else if (wave == 4) {
+    // position j: its partial sums are the row chunks of row block 0 and that block's column partial
+    nq_j = tile_nq(n, cs, 0, B.cw);
+    rp_j = B.RP[(long)((lane < nq_j) ? lane : 0) * B.ldp + j];
+    cp_j = B.CP[j];
+  } else {
+    const int which = wave - 5;
+    const int kc = (lane < ip) ? lane : 0;
+    const int ndch = (n - j + DCH - 1) / DCH;  // dot chunks of the symv launch of column jp
+    batch_issue<40>(B.DP, (unsigned)(which * NB + kc), 2u * NB, 0, 1, ndch, t_dp);
+    if (UPD) sidev = (which == 0) ? B.W[(long)kc * B.ldw + j] : A[(long)(j0 + kc) * ld + j];
+    float acc = batch_finish<40>(B.DP + which * NB + kc, 2 * NB, 0, 1, ndch, t_dp);
+    if (lane >= ip) acc = 0.f;
+    if (which == 0) {
+      s_dW[lane] = acc;
+      s_Wj[lane] = sidev;
+    } else {
+      s_dV[lane] = acc;
+      s_Vj[lane] = sidev;
+    }
+  }
+  float ypart = 0.f, upart = 0.f;
+  if (wave < 4)
+    ypart = batch_finish<3>(B.RP + r, B.ldp, part, NPART2, nq, t_rp) + batch_finish<20>(B.CP + r, B.ldp, part, NPART2, bmax + 1, t_cp);
+  float part_sp = batch_finish<4>(B.SP, 1, tid, 448, nsp, t_sp);
+  part_sp = wave_tree_sum(part_sp);
+  if (lane == 0) s_red[wave] = part_sp;
+  __syncthreads();
+
+  if (wave < 4) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int k = part + NPART2 * t;
+      if (k < ip) {
+        ypart -= vkv[t] * s_dW[k] + wkv[t] * s_dV[k];
+        if (UPD) upart += vkv[t] * s_Wj[k] + wkv[t] * s_Vj[k];
+      }
+    }
+    s_y[part][pl] = ypart;
+    if (UPD) s_u[part][pl] = upart;
+  } else if (wave == 4) {
+    const float vav = (((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) + ((s_red[4] + s_red[5]) + s_red[6]));
+    const bool kin = lane < ip;
+    const float cross = wave_tree_sum(kin ? s_dV[lane] * s_dW[lane] : 0.f);
+    const float alpha = -0.5f * tau * tau * (vav - 2.f * cross);
+    float yj = ((lane < nq_j) ? rp_j : 0.f) + ((lane == 0) ? cp_j : 0.f);
+    if (UPD && kin) yj -= s_Vj[lane] * s_dW[lane] + s_Wj[lane] * s_dV[lane];
+    yj = wave_tree_sum(yj);  // (only the update of column j uses it: UPD)
+    if (lane == 0) {
+      s_bc[0] = alpha;
+      s_bc[1] = tau * yj + alpha;  // v[j] = 1
+    }
+  }
+  __syncthreads();
+  if (tid >= APOS2) return;
+  // ---- combine the eight parts of position r (wave 0, lanes 0..31)
+  float w = 0.f, v = 0.f, u = 0.f;
+  if (live) {
+    const float y = ((s_y[0][pl] + s_y[1][pl]) + (s_y[2][pl] + s_y[3][pl])) + ((s_y[4][pl] + s_y[5][pl]) + (s_y[6][pl] + s_y[7][pl]));
+    if (UPD) u = ((s_u[0][pl] + s_u[1][pl]) + (s_u[2][pl] + s_u[3][pl])) + ((s_u[4][pl] + s_u[5][pl]) + (s_u[6][pl] + s_u[7][pl]));
+    v = (r == j) ? 1.f : xv * scale;
+    w = tau * y + s_bc[0] * v;
+    B.W[(long)ip * B.ldw + r] = w;
+    A[(long)jp * ld + r] = v;
+  }
+  if (!UPD) return;
+  double sq = 0.0;
+  if (live) {
+    const float x = xj - (u + (v * s_bc[1] + w));
+    A[(long)j * ld + r] = x;
+    if (r == j) d[j] = x;
+    if (r >= j + 2) sq = (double)x * (double)x;
+  }
+  for (int o = 16; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+  if (lane == 0) B.NP[blockIdx.x] = sq;
+}
+
+// ------------------------------------------------------------------------------------------
 // Column j: reflector scalars from the partial norms (every workgroup, same order), then
 //   tiles (b, q): rows c in [cs + 64 b, +64), positions [r0(b) + 1024 q, +1024), cs = j + 1:
 //       RP[q][c]  = sum_{r in tile, r >= c} A[c][r] v[r]
@@ -369,11 +504,11 @@ __global__ __launch_bounds__(512, CWT == 1024 ? 2 : 4) void sytrd_symv_kernel(co
   // branch with a full wait behind it.  Rows >= rows repeat the last row and meet v = 0.
   // wave 0 first asks for the partial norms and the pivot of the reflector (written by the previous launch): its
   // scalar chain then runs while the tile streams in, instead of starting one round trip after the tile arrived
-  double np_pre[3] = {0.0, 0.0, 0.0};
+  double np_pre[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
   float a0_pre = 0.f;
   if (wave == 0) {
 #pragma unroll
-    for (int u = 0; u < 3; ++u) {
+    for (int u = 0; u < 5; ++u) {
       const int t = lane + 64 * u;
       np_pre[u] = B.NP[(t < n_np) ? t : 0];
     }
@@ -406,8 +541,8 @@ __global__ __launch_bounds__(512, CWT == 1024 ? 2 : 4) void sytrd_symv_kernel(co
     // reflector scalars: fixed-order tree over the partial norms, every lane of wave 0 holds the result
     double xn = 0.0;
 #pragma unroll
-    for (int u = 0; u < 3; ++u) xn += (lane + 64 * u < n_np) ? np_pre[u] : 0.0;
-    for (int t = lane + 192; t < n_np; t += 64) xn += B.NP[t];
+    for (int u = 0; u < 5; ++u) xn += (lane + 64 * u < n_np) ? np_pre[u] : 0.0;
+    for (int t = lane + 320; t < n_np; t += 64) xn += B.NP[t];
     for (int o = 32; o > 0; o >>= 1) xn += __shfl_xor(xn, o);
     const float a0 = a0_pre;
     float beta = a0, tau = 0.f, scale = 0.f;
@@ -984,7 +1119,7 @@ size_t pmd_sytrd_workspace_bytes_impl(int n) {
   b += nbk * n4 * sizeof(float) + 256;                // CP
   b += (nq + 2) * (nbk + 2) * sizeof(float) + 256;    // SP
   b += (size_t)(n / DCH + 2) * 2 * NB * sizeof(float) + 256;  // DP
-  b += (size_t)(n / APOS + 2) * sizeof(double) + 256;  // NP
+  b += (size_t)(n / 32 + 2) * sizeof(double) + 256;  // NP (one per advance workgroup: 32 positions)
   b += 4096;
   return b;
 }
@@ -1006,7 +1141,7 @@ int pmd_sytrd_impl(pmd_ctx* ctx, int n, float* A, long lda, float* d, float* e, 
   B.CP = ar.take_n<float>(nbkmax * n4);
   B.SP = ar.take_n<float>((nqmax + 2) * (nbkmax + 2));
   B.DP = ar.take_n<float>((size_t)(n / DCH + 2) * 2 * NB);
-  B.NP = ar.take_n<double>((size_t)(n / APOS + 2));
+  B.NP = ar.take_n<double>((size_t)(n / 32 + 2));
   B.scal = ar.take_n<float>(16);
   if (ar.overflow) return pmd_fail(ctx, PMD_ERR_WORKSPACE, "pmd_sytrd", "workspace too small");
   hipStream_t st = ctx->stream;
@@ -1017,6 +1152,8 @@ int pmd_sytrd_impl(pmd_ctx* ctx, int n, float* A, long lda, float* d, float* e, 
   int cw_fixed = cwf ? atoi(cwf) : 512;
   if (cw_fixed != 256 && cw_fixed != 512 && cw_fixed != 1024) cw_fixed = 512;
   B.cw = CW;
+  const char* advf = getenv("PMD_SYTRD_ADVANCE");  // "old": 64 positions x 4 parts per workgroup
+  const bool adv_old = advf && !strcmp(advf, "old");
   const char* dly = getenv("PMD_SYMV_DELAY");
   B.delay = dly ? atoi(dly) : 0;
   // PMD_SYMV_PERSIST=N: N persistent workgroups for the large trailing blocks (PMD_SYMV_PERSIST_DB=0: single-buffered,
@@ -1035,11 +1172,15 @@ int pmd_sytrd_impl(pmd_ctx* ctx, int n, float* A, long lda, float* d, float* e, 
     const int nbc = std::min(NB, n - 1 - j0);
     for (int i = 0; i < nbc; ++i) {
       const int j = j0 + i;
-      const int ga = (n - j + APOS - 1) / APOS;
-      if (i == 0)
+      int ga = (n - j + APOS - 1) / APOS;  // workgroups of the advance launch = partial norms the symv sums
+      if (i == 0) {
         hipLaunchKernelGGL((sytrd_advance_kernel<false, false>), dim3(ga), dim3(320), 0, st, A, lda, n, j, j0, B, nsp, d);
-      else
+      } else if (adv_old) {
         hipLaunchKernelGGL((sytrd_advance_kernel<true, true>), dim3(ga), dim3(320), 0, st, A, lda, n, j, j0, B, nsp, d);
+      } else {
+        ga = (n - j + APOS2 - 1) / APOS2;
+        hipLaunchKernelGGL((sytrd_advance2_kernel<true>), dim3(ga), dim3(448), 0, st, A, lda, n, j, j0, B, nsp, d);
+      }
       const int cs = j + 1;
       const int nbk = (n - cs + BR - 1) / BR;
       const int npairs = (nbk + 1) / 2;
@@ -1073,7 +1214,10 @@ int pmd_sytrd_impl(pmd_ctx* ctx, int n, float* A, long lda, float* d, float* e, 
     }
     PMD_LAUNCH_CHECK(ctx, "sytrd panel");
     const int ts = j0 + nbc;
-    hipLaunchKernelGGL((sytrd_advance_kernel<true, false>), dim3((n - ts + APOS - 1) / APOS), dim3(320), 0, st, A, lda, n, ts, j0, B, nsp, d);
+    if (adv_old)
+      hipLaunchKernelGGL((sytrd_advance_kernel<true, false>), dim3((n - ts + APOS - 1) / APOS), dim3(320), 0, st, A, lda, n, ts, j0, B, nsp, d);
+    else
+      hipLaunchKernelGGL((sytrd_advance2_kernel<false>), dim3((n - ts + APOS2 - 1) / APOS2), dim3(448), 0, st, A, lda, n, ts, j0, B, nsp, d);
     PMD_LAUNCH_CHECK(ctx, "sytrd_advance_kernel");
     if (use_rocblas_syr2k) {
       PMD_BLAS(ctx, rocblas_ssyr2k(ctx->blas, rocblas_fill_lower, rocblas_operation_none, n - ts, nbc, &minus1,

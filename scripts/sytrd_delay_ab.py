@@ -11,7 +11,10 @@ ld = (n + 3) // 4 * 4
 S = torch.zeros((n, ld), device="cuda"); S[:, :n] = X @ X.T; del X
 d = torch.zeros(n, device="cuda"); e = torch.zeros(n, device="cuda"); tau = torch.zeros(n, device="cuda")
 for dl in (sys.argv[2:] or ["0", "4", "8", "12", "16", "0"]):
-    os.environ["PMD_SYMV_DELAY"] = dl
+    if dl in ("old", "new"):
+        os.environ["PMD_SYTRD_ADVANCE"] = dl
+    else:
+        os.environ["PMD_SYMV_DELAY"] = dl
     best = 1e9
     for rep in range(2):
         A = S.clone(); torch.cuda.synchronize(); t0 = time.perf_counter()
