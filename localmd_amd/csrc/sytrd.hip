@@ -51,7 +51,6 @@ struct sytrd_bufs {
   double* NP;   // per advance workgroup: partial sum of squares
   float* scal;  // beta, tau, scale of the current reflector
   int cw;       // tile width (positions) of the symv launch whose partials RP / CP / SP currently hold
-  int delay;    // start offset of the second workgroup of every CU in the symv, units of 1024 cycles
 };
 
 __device__ __forceinline__ int tile_r0(int cs, int b) { return (cs + b * BR) & ~3; }
@@ -162,9 +161,14 @@ __device__ unsigned long long g_adv_trace[1024 * 8];
   do {                                                                                        \
     if (FIN && UPD && j == PMD_SYMV_TRACE_J && threadIdx.x == 0 && blockIdx.x < 1024) g_adv_trace[blockIdx.x * 8 + (slot)] = wall_clock64(); \
   } while (0)
+#define ADV2_STAMP(slot)                                                                      \
+  do {                                                                                        \
+    if (UPD && j == PMD_SYMV_TRACE_J && threadIdx.x == 0 && blockIdx.x < 1024) g_adv_trace[blockIdx.x * 8 + (slot)] = wall_clock64(); \
+  } while (0)
 #else
 #define TRACE_STAMP(slot) do {} while (0)
 #define ADV_STAMP(slot) do {} while (0)
+#define ADV2_STAMP(slot) do {} while (0)
 #endif
 
 
@@ -328,6 +332,7 @@ __global__ __launch_bounds__(448) void sytrd_advance2_kernel(float* __restrict__
   const int ip = jp - j0;  // earlier panel columns seen by column jp
   const int cs = j;        // first row of the symv launch of column jp
   const int nbk = (n - cs + BR - 1) / BR;
+  ADV2_STAMP(0);
   float t_sp[4];
   batch_issue<4>(B.SP, 0u, 1u, tid, 448, nsp, t_sp);
   const float tau = B.scal[1], scale = B.scal[2];
@@ -380,13 +385,17 @@ __global__ __launch_bounds__(448) void sytrd_advance2_kernel(float* __restrict__
       s_Vj[lane] = sidev;
     }
   }
+  ADV2_STAMP(6);
   float ypart = 0.f, upart = 0.f;
   if (wave < 4)
     ypart = batch_finish<3>(B.RP + r, B.ldp, part, NPART2, nq, t_rp) + batch_finish<20>(B.CP + r, B.ldp, part, NPART2, bmax + 1, t_cp);
+  ADV2_STAMP(1);
   float part_sp = batch_finish<4>(B.SP, 1, tid, 448, nsp, t_sp);
+  ADV2_STAMP(2);
   part_sp = wave_tree_sum(part_sp);
   if (lane == 0) s_red[wave] = part_sp;
   __syncthreads();
+  ADV2_STAMP(3);
 
   if (wave < 4) {
 #pragma unroll
@@ -413,6 +422,7 @@ __global__ __launch_bounds__(448) void sytrd_advance2_kernel(float* __restrict__
     }
   }
   __syncthreads();
+  ADV2_STAMP(4);
   if (tid >= APOS2) return;
   // ---- combine the eight parts of position r (wave 0, lanes 0..31)
   float w = 0.f, v = 0.f, u = 0.f;
@@ -434,6 +444,7 @@ __global__ __launch_bounds__(448) void sytrd_advance2_kernel(float* __restrict__
   }
   for (int o = 16; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
   if (lane == 0) B.NP[blockIdx.x] = sq;
+  ADV2_STAMP(5);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -470,13 +481,6 @@ __global__ __launch_bounds__(512, CWT == 1024 ? 2 : 4) void sytrd_symv_kernel(co
   const int wg = blockIdx.y * gridDim.x + blockIdx.x;
   const bool is_dot = (int)blockIdx.y >= npairs;
   TRACE_STAMP(0);
-  // The workgroups of the first round start together and then stay in lockstep (trace: scripts/symv_trace.py):
-  // the two workgroups of a CU load at the same time and reduce at the same time, and the memory pipe idles
-  // 30 % of the launch.  The second workgroup of every CU (ids 256..511: the dispatcher fills every CU once
-  // before it fills a second slot) therefore starts half a period late.
-  if (wg >= 256 && wg < 512)
-    for (int w = 0; w < B.delay; ++w) __builtin_amdgcn_s_sleep(16);
-
   // ---- which tile: row blocks are paired (p, nbk-1-p) so that every grid row has about the same work
   int b = blockIdx.y, q = blockIdx.x;
   bool valid = !is_dot;
@@ -690,298 +694,6 @@ __global__ __launch_bounds__(512, CWT == 1024 ? 2 : 4) void sytrd_symv_kernel(co
   TRACE_STAMP(5);
 }
 
-// ------------------------------------------------------------------------------------------
-// The same product with persistent workgroups (512-position tiles): one workgroup per CU walks the tile
-// list with stride gridDim and holds TWO tiles in registers - the loads of the next tile are issued
-// before the current one is reduced, so the memory pipe never drains between tiles (the one-tile-per-
-// workgroup form alternates between a load phase and a reduce phase and reaches 4.3 TB/s).  The
-// reflector scalars are computed once per workgroup instead of once per tile.  Tile numbering, partial
-// sum layout (RP / CP / SP) and every summation order are those of sytrd_symv_kernel<512>, so the two
-// forms give bit-identical results.  Workgroups >= n_persist do the panel dot products.
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-template <bool DB>
-__global__ __launch_bounds__(512, DB ? 2 : 4) void sytrd_symv_persist_kernel(const float* __restrict__ A, long ld, int n, int j, int j0,
-                                                                    sytrd_bufs B, int n_np, int npairs, int nbk, int nqx,
-                                                                    int n_persist, float* __restrict__ e,
-                                                                    float* __restrict__ tau_out) {
-  constexpr int CWT = 512;
-  constexpr int NPG = CWT / 256, NRG = 8 / NPG, RPW = BR / NRG, LOGR = 4;
-  static_assert(RPW == 16, "tile shape");
-  __shared__ float s_v[BR];
-  __shared__ float s_row[NPG][BR];
-  __shared__ float s_col[NPG][NRG - 1][64][4];
-  __shared__ float s_red[8];
-  __shared__ float s_sc[4];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: row addresses become SGPR bases
-  const int wc = wave % NPG, rh = wave / NPG;
-  const int cs = j + 1;
-  const float* xr = A + (long)j * ld;
-  const bool is_dot = (int)blockIdx.x >= n_persist;
-  const int n4 = (n + 3) & ~3;
-  const int VT = nqx * npairs;
-
-
-  if (is_dot) {
-    if (wave == 0) {
-      double xn = 0.0;
-      for (int t = lane; t < n_np; t += 64) xn += B.NP[t];
-      for (int o = 32; o > 0; o >>= 1) xn += __shfl_xor(xn, o);
-      const float a0 = xr[cs];
-      float beta = a0, tau = 0.f, scale = 0.f;
-      if (xn > 0.0) {
-        const double nr = sqrt((double)a0 * (double)a0 + xn);
-        const double bt = (a0 >= 0.f) ? -nr : nr;
-        beta = (float)bt;
-        tau = (float)((bt - (double)a0) / bt);
-        scale = (float)(1.0 / ((double)a0 - bt));
-      }
-      if (lane == 0) {
-        s_sc[2] = scale;
-        if (blockIdx.x == 0) {
-          e[j] = beta;
-          tau_out[j] = tau;
-          B.scal[0] = beta;
-          B.scal[1] = tau;
-          B.scal[2] = scale;
-        }
-      }
-    }
-    __syncthreads();
-    const float scale = s_sc[2];
-    const int i = j - j0;
-    const int dchunk = (int)blockIdx.x - n_persist;
-    const int base = cs + dchunk * DCH;
-    if (base >= n || i == 0) return;
-    float vv[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int r = base + g * 64 + lane;
-      const float xg = xr[min(r, n - 1)];
-      vv[g] = (r < n) ? ((r == cs) ? 1.f : xg * scale) : 0.f;
-    }
-    for (int k = wave; k < i; k += 8) {
-      float aw = 0.f, av = 0.f;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int r = min(base + g * 64 + lane, n - 1);
-        aw += B.W[(long)k * B.ldw + r] * vv[g];
-        av += A[(long)(j0 + k) * ld + r] * vv[g];
-      }
-      for (int o = 32; o > 0; o >>= 1) {
-        aw += __shfl_xor(aw, o);
-        av += __shfl_xor(av, o);
-      }
-      if (lane == 0) {
-        B.DP[((long)dchunk * 2 + 0) * NB + k] = aw;
-        B.DP[((long)dchunk * 2 + 1) * NB + k] = av;
-      }
-    }
-    return;
-  }
-
-  float scale = 0.f;  // set after the first tile's loads are in flight (see below)
-  // virtual tile t -> (row block b, chunk q); tiles that do not exist get SP[t] = 0 (workgroup-uniform)
-  auto decode = [&](int t, int& b, int& q) -> bool {
-    b = t / nqx;
-    q = t - b * nqx;
-    const int nq_b = tile_nq(n, cs, b, CWT);
-    if (q >= nq_b) {
-      const int b2 = nbk - 1 - b;
-      q -= nq_b;
-      if (b2 == b || q >= tile_nq(n, cs, b2, CWT)) return false;
-      b = b2;
-    }
-    return true;
-  };
-  auto next_tile = [&](int t) -> int {
-    int b, q;
-    while (t < VT && !decode(t, b, q)) {
-      if (tid == 0) B.SP[t] = 0.f;
-      t += n_persist;
-    }
-    return t;
-  };
-  // all loads of a tile, unconditional (clamped row / position, masked at use)
-  // (dummy: no tile left - the loads stay unconditional, so that no register of the buffer becomes a phi that the
-  // allocator would have to copy, and re-read one cached row)
-  auto load = [&](int t, bool dummy, float4* a, float* vraw, float& xc) {
-    int b, q;
-    decode(t, b, q);
-    const int cb = cs + b * BR;
-    const int rows = dummy ? 1 : min(BR, n - cb);
-    const int r0 = tile_r0(cs, b);
-    const int pos = r0 + q * CWT + wc * 256 + lane * 4;
-    const unsigned boff = (unsigned)((pos < n4) ? pos : r0) * 4u;  // byte offset in the row: SGPR base + 32-bit VGPR offset
-#pragma unroll
-    for (int uu = 0; uu < RPW; ++uu) {
-      const char* rowp = reinterpret_cast<const char*>(A + (long)(cb + min(rh * RPW + uu, rows - 1)) * ld);  // wave-uniform
-      a[uu] = *reinterpret_cast<const float4*>(rowp + boff);
-    }
-#pragma unroll
-    for (int tt = 0; tt < 4; ++tt) {
-      const int r = pos + tt;
-      vraw[tt] = xr[(r < n && r > cs) ? r : cs];
-    }
-    const int c = cb + (tid & (BR - 1));
-    xc = xr[(c < n && c > cs) ? c : cs];
-  };
-  auto reduce = [&](int t, const float4* a, const float* vraw, float xc) {
-    int b, q;
-    decode(t, b, q);
-    const int cb = cs + b * BR;
-    const int rows = min(BR, n - cb);
-    const int r0 = tile_r0(cs, b);
-    const int pos = r0 + q * CWT + wc * 256 + lane * 4;
-    const bool ok = pos < n4;
-    float v4[4];
-#pragma unroll
-    for (int tt = 0; tt < 4; ++tt) {
-      const int r = pos + tt;
-      const bool in = r < n && r > cs;
-      v4[tt] = (r == cs) ? 1.f : (in ? vraw[tt] * scale : 0.f);
-    }
-    if (tid < BR) {
-      const int c = cb + tid;
-      const bool in = c < n && c > cs;
-      s_v[tid] = (c == cs) ? 1.f : (in ? xc * scale : 0.f);
-    }
-    lds_barrier();
-    const bool edge = (q == 0) || (r0 + (q + 1) * CWT > n);
-    float col[4] = {0.f, 0.f, 0.f, 0.f};
-    float pr[RPW];
-    if (edge) {
-#pragma unroll
-      for (int uu = 0; uu < RPW; ++uu) {
-        const int c = cb + rh * RPW + uu;
-        const float vc = s_v[rh * RPW + uu];
-        const float m0 = (pos + 0 < n) ? a[uu].x : 0.f, m1 = (pos + 1 < n) ? a[uu].y : 0.f,
-                    m2 = (pos + 2 < n) ? a[uu].z : 0.f, m3 = (pos + 3 < n) ? a[uu].w : 0.f;
-        pr[uu] = (((pos + 0 >= c) ? m0 * v4[0] : 0.f) + ((pos + 1 >= c) ? m1 * v4[1] : 0.f)) +
-                 (((pos + 2 >= c) ? m2 * v4[2] : 0.f) + ((pos + 3 >= c) ? m3 * v4[3] : 0.f));
-        col[0] += (pos + 0 > c) ? m0 * vc : 0.f;
-        col[1] += (pos + 1 > c) ? m1 * vc : 0.f;
-        col[2] += (pos + 2 > c) ? m2 * vc : 0.f;
-        col[3] += (pos + 3 > c) ? m3 * vc : 0.f;
-      }
-    } else {
-#pragma unroll
-      for (int uu = 0; uu < RPW; ++uu) {
-        const float vc = s_v[rh * RPW + uu];
-        pr[uu] = (a[uu].x * v4[0] + a[uu].y * v4[1]) + (a[uu].z * v4[2] + a[uu].w * v4[3]);
-        col[0] += a[uu].x * vc;
-        col[1] += a[uu].y * vc;
-        col[2] += a[uu].z * vc;
-        col[3] += a[uu].w * vc;
-      }
-    }
-#pragma unroll
-    for (int st = 0; st < LOGR; ++st) {
-      const int off = 32 >> st, half = (RPW / 2) >> st;
-      const bool upper = (lane & off) != 0;
-#pragma unroll
-      for (int tt = 0; tt < half; ++tt) {
-        const float send = upper ? pr[tt] : pr[tt + half];
-        const float keep = upper ? pr[tt + half] : pr[tt];
-        pr[tt] = keep + __shfl_xor(send, off);
-      }
-    }
-#pragma unroll
-    for (int off = 32 >> LOGR; off > 0; off >>= 1) pr[0] += __shfl_xor(pr[0], off);
-    if ((lane & ((64 >> LOGR) - 1)) == 0) s_row[wc][rh * RPW + (lane >> (6 - LOGR))] = pr[0];
-    if (rh > 0) {
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt) s_col[wc][rh - 1][lane][tt] = col[tt];
-    }
-    lds_barrier();
-    float spart = 0.f;
-    if (tid < rows) {
-      float rs = s_row[0][tid];
-#pragma unroll
-      for (int g = 1; g < NPG; ++g) rs += s_row[g][tid];
-      B.RP[(long)q * B.ldp + cb + tid] = rs;
-      spart = s_v[tid] * rs;
-    }
-    if (rh == 0) {
-#pragma unroll
-      for (int g = 0; g < NRG - 1; ++g)
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) col[tt] += s_col[wc][g][lane][tt];
-      spart += (v4[0] * col[0] + v4[1] * col[1]) + (v4[2] * col[2] + v4[3] * col[3]);
-      if (ok) *reinterpret_cast<float4*>(B.CP + (long)b * B.ldp + pos) = make_float4(col[0], col[1], col[2], col[3]);
-    }
-    for (int o = 32; o > 0; o >>= 1) spart += __shfl_xor(spart, o);
-    if (lane == 0) s_red[wave] = spart;
-    lds_barrier();
-    if (tid == 0) {
-      float tot = 0.f;
-      for (int tt = 0; tt < 8; ++tt) tot += s_red[tt];
-      B.SP[t] = tot;
-    }
-  };
-
-  float4 a0[RPW];
-  float v0[4], x0;
-  int t0 = next_tile((int)blockIdx.x);
-  if (t0 >= VT) return;
-  // single-buffered form (two workgroups per CU): the second half of the workgroups computes the scalars BEFORE
-  // its first loads, which puts the two workgroups of a CU out of phase - one loads while the other reduces
-  const bool late = !DB && (int)blockIdx.x >= n_persist / 2;
-  if (!late) load(t0, false, a0, v0, x0);
-  // reflector scalars, behind the first tile's loads (the partial norms were written by the previous launch: a
-  // dependent chain of ~2 us that would otherwise delay every load of this launch)
-  if (wave == 0) {
-    double xn = 0.0;
-    for (int t = lane; t < n_np; t += 64) xn += B.NP[t];
-    for (int o = 32; o > 0; o >>= 1) xn += __shfl_xor(xn, o);
-    const float a0 = xr[cs];
-    float beta = a0, tau = 0.f, scale = 0.f;
-    if (xn > 0.0) {
-      const double nr = sqrt((double)a0 * (double)a0 + xn);
-      const double bt = (a0 >= 0.f) ? -nr : nr;
-      beta = (float)bt;
-      tau = (float)((bt - (double)a0) / bt);
-      scale = (float)(1.0 / ((double)a0 - bt));
-    }
-    if (lane == 0) {
-      s_sc[2] = scale;
-      if (blockIdx.x == 0) {
-        e[j] = beta;
-        tau_out[j] = tau;
-        B.scal[0] = beta;
-        B.scal[1] = tau;
-        B.scal[2] = scale;
-      }
-    }
-  }
-  __syncthreads();
-  scale = s_sc[2];
-  if constexpr (!DB) {
-    if (late) load(t0, false, a0, v0, x0);
-    for (;;) {
-      reduce(t0, a0, v0, x0);
-      t0 = next_tile(t0 + n_persist);
-      if (t0 >= VT) break;
-      load(t0, false, a0, v0, x0);
-    }
-    return;
-  }
-  float4 a1[RPW];
-  float v1[4], x1;
-  for (;;) {
-    const int t1 = next_tile(t0 + n_persist);
-    load(t1 < VT ? t1 : t0, t1 >= VT, a1, v1, x1);
-    reduce(t0, a0, v0, x0);
-    if (t1 >= VT) break;
-    t0 = next_tile(t1 + n_persist);
-    load(t0 < VT ? t0 : t1, t0 >= VT, a0, v0, x0);
-    reduce(t1, a1, v1, x1);
-    if (t0 >= VT) break;
-  }
-}
-
 // Panel update of the trailing block (slatrd's A22 -= V W^T + W V^T) on the triangle that is read:
 //   T[c][r] -= sum_k V_k[c] W_k[r] + W_k[c] V_k[r],   ts <= c <= r < n,  k < nbc <= 64.
 // One workgroup = one 64 x 64 tile (I <= J); wave w owns rows 16 w .. 16 w + 15 of it in four 16 x 16 fp32 MFMA
@@ -1145,6 +857,7 @@ int pmd_sytrd_impl(pmd_ctx* ctx, int n, float* A, long lda, float* d, float* e, 
   B.scal = ar.take_n<float>(16);
   if (ar.overflow) return pmd_fail(ctx, PMD_ERR_WORKSPACE, "pmd_sytrd", "workspace too small");
   hipStream_t st = ctx->stream;
+
   const char* s2k = getenv("PMD_SYR2K");
   const bool use_rocblas_syr2k = s2k && !strcmp(s2k, "rocblas");
   const char* cwf = getenv("PMD_SYMV_CW");
@@ -1154,18 +867,6 @@ int pmd_sytrd_impl(pmd_ctx* ctx, int n, float* A, long lda, float* d, float* e, 
   B.cw = CW;
   const char* advf = getenv("PMD_SYTRD_ADVANCE");  // "old": 64 positions x 4 parts per workgroup
   const bool adv_old = advf && !strcmp(advf, "old");
-  const char* dly = getenv("PMD_SYMV_DELAY");
-  B.delay = dly ? atoi(dly) : 0;
-  // PMD_SYMV_PERSIST=N: N persistent workgroups for the large trailing blocks (PMD_SYMV_PERSIST_DB=0: single-buffered,
-  // two per CU, out of phase).  Off by default: measured at n = 10^4 (scripts/sytrd_ab.py) both forms
-  // run a launch at n' ~ 10^4 in 41 us against 43.5 us, lose at n' < 7000 (6 tiles per workgroup: imbalance) and leave
-  // the whole reduction at 285 ms - the product is bound by the bytes a CU keeps in flight (half of its register
-  // file either way), not by the alternation of load and reduce phases.
-  const char* pf = getenv("PMD_SYMV_PERSIST");
-  const int persist_wgs = (pf && atoi(pf) > 0) ? atoi(pf) : 256;
-  const bool persist = pf && atoi(pf) > 0;
-  const char* pdb = getenv("PMD_SYMV_PERSIST_DB");
-  const bool persist_db = !(pdb && atoi(pdb) == 0);
   const float one = 1.f, minus1 = -1.f;
   int nsp = 0;
   for (int j0 = 0; j0 < n - 1; j0 += NB) {
@@ -1194,15 +895,7 @@ int pmd_sytrd_impl(pmd_ctx* ctx, int n, float* A, long lda, float* d, float* e, 
       {
         // with profiling on, every 64th column's product is timed on its own (bench.py: roofline of this kernel)
         pmd_prof_scope sample__((ctx->profile && (j & 63) == 32) ? ctx : nullptr, "sytrd_symv_sample");
-        if (persist && cw == 512 && nqx * npairs > 2 * persist_wgs) {
-          // large trailing blocks: persistent, register double-buffered form (bit-identical partial sums)
-          if (persist_db)
-            hipLaunchKernelGGL(sytrd_symv_persist_kernel<true>, dim3(persist_wgs + ndch), dim3(512), 0, st, A, lda, n, j, j0,
-                               B, ga, npairs, nbk, nqx, persist_wgs, e, tau);
-          else
-            hipLaunchKernelGGL(sytrd_symv_persist_kernel<false>, dim3(persist_wgs + ndch), dim3(512), 0, st, A, lda, n, j, j0,
-                               B, ga, npairs, nbk, nqx, persist_wgs, e, tau);
-        } else if (cw == 256)
+        if (cw == 256)
           hipLaunchKernelGGL(sytrd_symv_kernel<256>, dim3(nqx, npairs + drows), dim3(512), 0, st, A, lda, n, j, j0, B, ga, npairs, nbk, e, tau);
         else if (cw == 512)
           hipLaunchKernelGGL(sytrd_symv_kernel<512>, dim3(nqx, npairs + drows), dim3(512), 0, st, A, lda, n, j, j0, B, ga, npairs, nbk, e, tau);
