@@ -150,7 +150,9 @@ constexpr int APOS = 64;
 #ifdef PMD_SYMV_TRACE
 // Debug build only (PMD_EXTRA_FLAGS=-DPMD_SYMV_TRACE): wall-clock stamps (100 MHz) of the phases of every workgroup
 // of the symv launch of column PMD_SYMV_TRACE_J, read back with pmdk_symv_trace (scripts/symv_trace.py).
+#ifndef PMD_SYMV_TRACE_J
 #define PMD_SYMV_TRACE_J 32
+#endif
 __device__ unsigned long long g_symv_trace[4096 * 8];
 #define TRACE_STAMP(slot)                                                                     \
   do {                                                                                        \

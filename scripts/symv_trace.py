@@ -1,6 +1,6 @@
 """Phase timeline of the workgroups of one symv launch (column 32 of an n = 9999 tridiagonalisation).
-Needs the trace build of the library:
-    hipcc ... -DPMD_SYMV_TRACE -c sytrd.hip  (see scripts/README.md), PMD_HIP_LIB=localmd_amd/libpmd_hip_trace.so
+Needs the trace build of the library (bash scripts/build_trace_lib.sh [column]):
+
 Stamps (100 MHz wall clock) per workgroup: 0 entry, 1 loads issued, 2 scalars ready (barrier), 3 tile products done
 (= loads arrived), 4 cross-lane reduce + barrier done, 5 partial sums stored."""
 import ctypes as C
