@@ -21,6 +21,16 @@ int pmd_ctx_create(int device, void* hip_stream, pmd_ctx** out) {
   ctx->tables = nullptr;
   ctx->scratch = nullptr;
   ctx->scratch_bytes = 0;
+  ctx->split_ws = nullptr;
+  ctx->split_ws_bytes = 0;
+  {
+    // PMD_GEMM_SPLIT=3|6 (opt-in, default off): large fp32 products from bf16 pieces, see pmd_gemm_rm
+    const char* gs = getenv("PMD_GEMM_SPLIT");
+    const int v = gs ? atoi(gs) : 0;
+    ctx->gemm_split = (v == 3 || v == 6) ? v : 0;
+    const char* gm = getenv("PMD_GEMM_SPLIT_MIN_GFLOP");
+    ctx->gemm_split_min_flop = (gm ? atof(gm) : 500.0) * 1e9;
+  }
   ctx->blas = nullptr;
   ctx->err[0] = 0;
   ctx->profile = false;
@@ -38,6 +48,7 @@ int pmd_ctx_destroy(pmd_ctx* ctx) {
   hipSetDevice(ctx->device);
   if (ctx->tables) hipFree(ctx->tables);
   if (ctx->scratch) hipFree(ctx->scratch);
+  if (ctx->split_ws) hipFree(ctx->split_ws);
   if (ctx->blas) rocblas_destroy_handle(ctx->blas);
   delete ctx;
   return PMD_OK;

@@ -22,10 +22,80 @@
   } while (0)
 
 // row-major C(m x n) = alpha * op(A) * op(B) + beta * C
+// ---------------------------------------------------------------- split products (opt-in) --
+// PMD_GEMM_SPLIT=3|6: an fp32 product as a sum of bf16-piece products on the bf16 MFMA path, fp32 accumulation.
+// x = x1 + x2 (+ x3) with bf16 pieces (8 mantissa bits each).  "3": a1 b1 + a1 b2 + a2 b1 (drops terms of relative
+// size 2^-16 with random signs); "6": adds a1 b3 + a2 b2 + a3 b1 (drops 2^-24: below fp32 rounding).  Measured on the
+// shapes of the global stage (scripts/gemm_split_probe.hip, error against fp64 on sampled entries, relative rms):
+// sgemm 79 ms / 3.6e-6, "3" 32 ms / 4.0e-6, "6" 64 ms / 1.4e-6.  Default off: the bench line is plain sgemm.
+__global__ void split_bf16_kernel(const float* __restrict__ src, long ld, long rows, long cols, rocblas_bfloat16* __restrict__ p1,
+                                  rocblas_bfloat16* __restrict__ p2, rocblas_bfloat16* __restrict__ p3) {
+  const long total = rows * cols;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / cols, c = i - r * cols;
+    const float x = src[r * ld + c];
+    const unsigned u1 = (__float_as_uint(x) + 0x7fffu + ((__float_as_uint(x) >> 16) & 1u)) & 0xffff0000u;  // round to nearest even
+    const float f1 = __uint_as_float(u1);
+    const float r1 = x - f1;
+    const unsigned u2 = (__float_as_uint(r1) + 0x7fffu + ((__float_as_uint(r1) >> 16) & 1u)) & 0xffff0000u;
+    const float f2 = __uint_as_float(u2);
+    p1[i].data = (uint16_t)(u1 >> 16);
+    p2[i].data = (uint16_t)(u2 >> 16);
+    if (p3) {
+      const float r2 = r1 - f2;
+      const unsigned u3 = (__float_as_uint(r2) + 0x7fffu + ((__float_as_uint(r2) >> 16) & 1u)) & 0xffff0000u;
+      p3[i].data = (uint16_t)(u3 >> 16);
+    }
+  }
+}
+
+static int gemm_rm_split(pmd_ctx* ctx, int transA, int transB, int m, int n, int k, float alpha, const float* A, long lda,
+                         const float* B, long ldb, float beta, float* C, long ldc) {
+  pmd_prof_scope prof__(ctx, "gemm_split_bf16");
+  const int np = (ctx->gemm_split == 6) ? 3 : 2;
+  const long a_rows = transA ? k : m, a_cols = transA ? m : k, b_rows = transB ? n : k, b_cols = transB ? k : n;
+  const size_t na = (size_t)a_rows * a_cols, nb = (size_t)b_rows * b_cols;
+  const size_t need = (na + nb) * np * sizeof(rocblas_bfloat16) + 4096;
+  if (ctx->split_ws_bytes < need) {
+    PMD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->split_ws) (void)hipFree(ctx->split_ws);
+    ctx->split_ws = nullptr;
+    ctx->split_ws_bytes = 0;
+    PMD_HIP(ctx, hipMalloc(&ctx->split_ws, need));
+    ctx->split_ws_bytes = need;
+  }
+  rocblas_bfloat16* ap[3] = {nullptr, nullptr, nullptr};
+  rocblas_bfloat16* bp[3] = {nullptr, nullptr, nullptr};
+  rocblas_bfloat16* w = (rocblas_bfloat16*)ctx->split_ws;
+  for (int i = 0; i < np; ++i) { ap[i] = w; w += na; }
+  for (int i = 0; i < np; ++i) { bp[i] = w; w += nb; }
+  hipLaunchKernelGGL(split_bf16_kernel, dim3(8192), dim3(256), 0, ctx->stream, A, lda, a_rows, a_cols, ap[0], ap[1], ap[2]);
+  hipLaunchKernelGGL(split_bf16_kernel, dim3(8192), dim3(256), 0, ctx->stream, B, ldb, b_rows, b_cols, bp[0], bp[1], bp[2]);
+  PMD_LAUNCH_CHECK(ctx, "split_bf16_kernel");
+  // smallest terms first; the pieces are compact row-major arrays (leading dimension = their column count)
+  const int term3[3][2] = {{1, 0}, {0, 1}, {0, 0}};
+  const int term6[6][2] = {{2, 0}, {1, 1}, {0, 2}, {1, 0}, {0, 1}, {0, 0}};
+  const int nt = (np == 3) ? 6 : 3;
+  const float one = 1.f;
+  for (int t = 0; t < nt; ++t) {
+    const int ia = (np == 3) ? term6[t][0] : term3[t][0], ib = (np == 3) ? term6[t][1] : term3[t][1];
+    const float* bt = (t == 0) ? &beta : &one;
+    PMD_BLAS(ctx, rocblas_gemm_ex(ctx->blas, transB ? rocblas_operation_transpose : rocblas_operation_none,
+                                  transA ? rocblas_operation_transpose : rocblas_operation_none, n, m, k, &alpha, bp[ib],
+                                  rocblas_datatype_bf16_r, (rocblas_int)b_cols, ap[ia], rocblas_datatype_bf16_r,
+                                  (rocblas_int)a_cols, bt, C, rocblas_datatype_f32_r, (rocblas_int)ldc, C,
+                                  rocblas_datatype_f32_r, (rocblas_int)ldc, rocblas_datatype_f32_r,
+                                  rocblas_gemm_algo_standard, 0, 0));
+  }
+  return PMD_OK;
+}
+
 int pmd_gemm_rm(pmd_ctx* ctx, int transA, int transB, int m, int n, int k, float alpha, const float* A, long lda,
                 const float* B, long ldb, float beta, float* C, long ldc) {
-  pmd_prof_scope prof__(ctx, "rocblas_sgemm");
   if (m <= 0 || n <= 0) return PMD_OK;
+  if (ctx->gemm_split && k > 0 && 2.0 * m * (double)n * k >= ctx->gemm_split_min_flop)
+    return gemm_rm_split(ctx, transA, transB, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc);
+  pmd_prof_scope prof__(ctx, "rocblas_sgemm");
   PMD_BLAS(ctx, rocblas_sgemm(ctx->blas, transB ? rocblas_operation_transpose : rocblas_operation_none,
                               transA ? rocblas_operation_transpose : rocblas_operation_none, n, m, k, &alpha, B,
                               (rocblas_int)ldb, A, (rocblas_int)lda, &beta, C, (rocblas_int)ldc));

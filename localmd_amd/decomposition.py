@@ -23,6 +23,7 @@ frame sample, frame windows) are rank 0's.
 import datetime
 import math
 import sys
+import os
 import time
 from typing import Callable, Optional
 
@@ -861,7 +862,9 @@ def localmd_decomposition(
             # device copy of R only where rows are exchanged between ranks; rank 0's own rows go straight to the host
             # Zero copy only for the large case it was measured on: for small outputs rocBLAS may pick split-K kernels
             # that read-modify-write C, which is ruinous across PCIe (58 ms instead of 1 ms at 5015 x 1999).
-            zero_copy = (not shard or dist.rank == 0) and m_used >= 8192 and Rc * nk * 4 >= 2 ** 30
+            # (not with PMD_GEMM_SPLIT: its passes accumulate into C, which must then live in HBM)
+            split_gemm = os.environ.get("PMD_GEMM_SPLIT", "0") in ("3", "6")
+            zero_copy = (not shard or dist.rank == 0) and m_used >= 8192 and Rc * nk * 4 >= 2 ** 30 and not split_gemm
             R_out = torch.empty((Rc, nk), dtype=torch.float32, device=ctx.device) if (shard or not zero_copy) else None
             s_out = torch.empty((nk,), dtype=torch.float32, device=ctx.device)
             Vt_out = torch.empty((nk, T), dtype=torch.float32, device=ctx.device)
