@@ -514,3 +514,36 @@ def test_sytrd_advance_forms_agree(gpu_ctx, monkeypatch):
     ev0 = eigvalsh_tridiagonal(d0.astype(np.float64), e0.astype(np.float64))
     assert np.abs(ev1 - ev0).max() < 2e-5 * np.abs(ev0).max()
     assert abs(d1.sum() - d0.sum()) < 1e-5 * abs(d0.sum())
+
+
+@pytest.mark.parametrize("mode", ["3", "6"])
+def test_gemm_split_option(mode, monkeypatch):
+    """PMD_GEMM_SPLIT (opt-in): row-major C = alpha op(A) op(B) + beta C from bf16 pieces with fp32 accumulation, all four
+    transpose combinations, leading dimensions larger than the rows; error against fp64 well below bf16 rounding."""
+    torch = _t()
+    from localmd_amd._lib import Context
+
+    monkeypatch.setenv("PMD_GEMM_SPLIT", mode)
+    monkeypatch.setenv("PMD_GEMM_SPLIT_MIN_GFLOP", "0")
+    ctx = Context(0)  # the option is read when a context is created
+    try:
+        rng = np.random.default_rng(3)
+        m, n, k = 192, 160, 3000
+        for ta, tb in ((0, 0), (1, 0), (0, 1), (1, 1)):
+            a = rng.standard_normal((k, m) if ta else (m, k)).astype(np.float32)
+            b = rng.standard_normal((n, k) if tb else (k, n)).astype(np.float32)
+            c0 = rng.standard_normal((m, n)).astype(np.float32)
+            lda, ldb, ldc = a.shape[1] + 4, b.shape[1] + 8, n + 4
+            ab = np.zeros((a.shape[0], lda), np.float32); ab[:, :a.shape[1]] = a
+            bb = np.zeros((b.shape[0], ldb), np.float32); bb[:, :b.shape[1]] = b
+            cb = np.zeros((m, ldc), np.float32); cb[:, :n] = c0
+            ad, bd, cd = dev(ctx, ab), dev(ctx, bb), dev(ctx, cb)
+            ctx.call("pmd_gemm", ta, tb, m, n, k, 0.5, P(ad), lda, P(bd), ldb, -2.0, P(cd), ldc)
+            ctx.sync()
+            ref = 0.5 * ((a.T if ta else a).astype(np.float64) @ (b.T if tb else b).astype(np.float64)) - 2.0 * c0
+            got = cd.cpu().numpy()[:, :n]
+            err = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+            assert err < (2e-5 if mode == "3" else 2e-6), (ta, tb, err)
+            assert np.all(cd.cpu().numpy()[:, n:] == 0)
+    finally:
+        ctx.close()
