@@ -213,14 +213,20 @@ __global__ __launch_bounds__(256) void standardize_transpose_kernel(const float*
   const long c = c0 + tx;
   const float mu = (c < D) ? mean[c] : 0.f;
   const float sg = (c < D) ? stdv[c] : 1.f;
-  for (int r = ty; r < 64; r += 4) {
-    const int f = f0 + r;
-    float v = 0.f;
-    if (f < nf && c < D) {
-      const long t = frames ? (long)frames[f] : (long)f;
-      v = (Y[t * D + c] - mu) / sg;
-    }
-    tile[r][tx] = v;
+  // the 16 loads of a thread are unconditional (clamped frame / pixel, masked value) and issued back to back: a
+  // guarded load compiles to a branch with a full wait behind it
+  const long cc = (c < D) ? c : D - 1;
+  float y[16];
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int f = min(f0 + ty + 4 * u, nf - 1);
+    const long t = frames ? (long)frames[f] : (long)f;
+    y[u] = Y[t * D + cc];
+  }
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int r = ty + 4 * u;
+    tile[r][tx] = (f0 + r < nf && c < D) ? (y[u] - mu) / sg : 0.f;
   }
   __syncthreads();
   for (int r = ty; r < 64; r += 4) {
