@@ -676,6 +676,92 @@ __global__ __launch_bounds__(256) void gram_apply_kernel(const float* __restrict
   }
 }
 
+// The same product on the fp32 MFMA path: a workgroup owns tile a x 256 columns (a wave 64 of them).  Per neighbour
+// block the (rank-masked) G block goes through LDS as the A operand (m = component of tile a, k = component of the
+// neighbour), a lane's float4 of M row cp0 + k is the B operand of four N tiles at once (N tile s = columns
+// 4 n + s: the permutation is undone by the float4 store of the four accumulators).  16 x CT x 4 accumulators.
+typedef float ga_f32x4 __attribute__((ext_vector_type(4)));
+constexpr int GA_LD = 80;  // g[cp][c] row length: 80 = 16 mod 64, the four k rows of a fragment hit disjoint banks
+
+template <int CT>
+__global__ __launch_bounds__(256) void gram_apply_mfma_kernel(const float* __restrict__ Gblk, const float* __restrict__ Gbg,
+                                                              const int* __restrict__ nbr_ptr, const int* __restrict__ nbr,
+                                                              const int* __restrict__ col_off, const int* __restrict__ ranks,
+                                                              const float* __restrict__ M, long ldm, int ncols,
+                                                              float* __restrict__ GM, long ldgm) {
+  __shared__ float g[64][GA_LD];
+  const int a = blockIdx.y;
+  const int ra = ranks[a];
+  if (ra == 0) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n16 = lane & 15, kk = lane >> 4;
+  const int x0 = blockIdx.x * 256 + wave * 64 + 4 * n16;
+  const long xc = (x0 + 3 < ldm) ? x0 : 0;  // idle lanes read valid columns; their results are not stored
+  ga_f32x4 acc[CT][4];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int sx = 0; sx < 4; ++sx) acc[ct][sx] = (ga_f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int e = nbr_ptr[a]; e < nbr_ptr[a + 1]; ++e) {
+    const int row0 = nbr[4 * e], rb = nbr[4 * e + 1], blk = nbr[4 * e + 2], flags = nbr[4 * e + 3];
+    const float* src = (flags & 2) ? Gbg + (long)blk * 4096 : Gblk + (long)blk * 4096;
+    __syncthreads();
+    // (only the part the MFMAs below read: cp < round_up(rb, 16), c < round_up(ra, 16); consecutive threads read
+    // consecutive addresses of the stored block in either orientation)
+    const int cpn = (rb + 15) & ~15, cn = (ra + 15) & ~15;
+    if (flags & 1) {
+      for (int i = threadIdx.x; i < cpn * cn; i += 256) {
+        const int cp = i / cn, c = i - cp * cn;
+        const float v = src[cp * 64 + c];
+        g[cp][c] = (cp < rb && c < ra) ? v : 0.f;  // masked: rows / columns beyond the ranks hold other tiles' data
+      }
+    } else {
+      for (int i = threadIdx.x; i < cpn * cn; i += 256) {
+        const int c = i / cpn, cp = i - c * cpn;
+        const float v = src[c * 64 + cp];
+        g[cp][c] = (cp < rb && c < ra) ? v : 0.f;
+      }
+    }
+    __syncthreads();
+    // 16 rows of M (four k steps) per batch, all four loads in flight at once, unconditional (rows clamped into the
+    // block; the masked G makes their contribution zero)
+    const float* mp = M + (long)row0 * ldm + xc;
+    for (int cp0 = 0; cp0 < rb; cp0 += 16) {
+      ga_f32x4 b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) b[u] = *reinterpret_cast<const ga_f32x4*>(mp + (long)min(cp0 + 4 * u + kk, rb - 1) * ldm);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (cp0 + 4 * u < rb) {  // workgroup-uniform
+#pragma unroll
+          for (int ct = 0; ct < CT; ++ct) {
+            if (16 * ct < ra) {  // workgroup-uniform: component tiles beyond this tile's rank are skipped
+              const float av = g[cp0 + 4 * u + kk][16 * ct + n16];
+#pragma unroll
+              for (int sx = 0; sx < 4; ++sx) acc[ct][sx] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[u][sx], acc[ct][sx], 0, 0, 0);
+            }
+          }
+        }
+      }
+    }
+  }
+  if (x0 >= ncols) return;
+  const long off = col_off[a];
+#pragma unroll
+  for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = 16 * ct + 4 * kk + i;
+      if (c >= ra) continue;
+      float* o = GM + (off + c) * ldgm + x0;
+      if (x0 + 3 < ncols) {
+        *reinterpret_cast<ga_f32x4*>(o) = (ga_f32x4){acc[ct][0][i], acc[ct][1][i], acc[ct][2][i], acc[ct][3][i]};
+      } else {
+        for (int sx = 0; sx < 4 && x0 + sx < ncols; ++sx) o[sx] = acc[ct][sx][i];
+      }
+    }
+}
+
 // blocks: Gblk [n_pairs][64][64], Gbg [n_tiles][64][64], Gstrip [K][ldgs] (ldgs >= Rt + K)
 int pmd_gram_blocks_impl(pmd_ctx* ctx, const float* Uw, int dpad, int b1, int b2, const int* pix, const int* pairs,
                          int n_pairs, const int* origins, const int* col_off, const int* ranks, int n_tiles, int Rt,
@@ -704,7 +790,20 @@ int pmd_gram_apply_impl(pmd_ctx* ctx, const float* Gblk, const float* Gbg, const
   {
     pmd_prof_scope prof__(ctx, "gram_apply");
     dim3 grid((ncols + 255) / 256, n_tiles);
-    if (max_rank <= 16)
+    const char* gam = getenv("PMD_GRAM_APPLY_MFMA");
+    const bool mfma_ok = !(gam && atoi(gam) == 0) && ldm % 4 == 0 && ldgm % 4 == 0 && ((uintptr_t)M & 15) == 0 &&
+                         ((uintptr_t)GM & 15) == 0 && max_rank <= 64;
+    if (mfma_ok) {
+      const int ct = (max_rank + 15) / 16;
+#define GA_LAUNCH(CT_)                                                                                                   \
+  hipLaunchKernelGGL(gram_apply_mfma_kernel<CT_>, grid, dim3(256), 0, ctx->stream, Gblk, Gbg, nbr_ptr, nbr, col_off, ranks, \
+                     M, ldm, ncols, GM, ldgm)
+      if (ct <= 1) GA_LAUNCH(1);
+      else if (ct == 2) GA_LAUNCH(2);
+      else if (ct == 3) GA_LAUNCH(3);
+      else GA_LAUNCH(4);
+#undef GA_LAUNCH
+    } else if (max_rank <= 16)
       hipLaunchKernelGGL(gram_apply_kernel<16>, grid, dim3(256), 0, ctx->stream, Gblk, Gbg, nbr_ptr, nbr, col_off, ranks,
                          M, ldm, ncols, GM, ldgm);
     else if (max_rank <= 32)
