@@ -25,6 +25,8 @@ CONFIGS = {
     "512x512x10000_b20": dict(T=10000, d1=512, d2=512, block=20, frames=10000, max_components=50),
     # spatial size / block of BASELINE config 4 with a time axis that fits one GPU next to its working copies
     "1024x1024x2000_b32": dict(T=2000, d1=1024, d2=1024, block=32, frames=2000, max_components=50),
+    # the same with a longer time axis (33.5 GB movie: element counts beyond 2^31 in every movie-sized array)
+    "1024x1024x8000_b32": dict(T=8000, d1=1024, d2=1024, block=32, frames=8000, max_components=50),
     # block / overlap of BASELINE config 5 on a quarter of its field of view
     "1024x1024x1000_b16": dict(T=1000, d1=1024, d2=1024, block=16, frames=1000, max_components=50),
 }

@@ -144,6 +144,23 @@ def test_large_tiles_1024x1024_b32(gpu_ctx):
     gpu_ctx.release_workspace()
 
 
+def test_beyond_2g_elements_1024x1024x8000_b32(gpu_ctx):
+    """33.5 GB movie: every movie-sized array has more than 2^31 elements (64-bit indexing in the movie passes, the tile
+    kernels and the projection), R = 1.1e5 > frames, eigenproblem of order 7999."""
+    import torch
+
+    free, total = torch.cuda.mem_get_info()
+    if total < 250 * 2 ** 30:
+        pytest.skip("needs an MI355X-class HBM capacity")
+    T, d1, d2, block = 8000, 1024, 1024, 32
+    pmd, diag, noisy = _decompose(gpu_ctx, T, d1, d2, block, 50)
+    assert len(diag["tile_ranks"]) == 63 * 63 and diag["rank_before"] > diag["crop"]
+    _check_properties(pmd, diag, noisy, T, d1, d2, block)
+    del pmd, noisy
+    gpu_ctx.release_workspace()
+    torch.cuda.empty_cache()
+
+
 def test_synthetic_slab_source_matches_whole_movie(gpu_ctx):
     """A band of FOV rows generated on its own equals the same rows of the whole synthetic movie."""
     import torch
