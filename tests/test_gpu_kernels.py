@@ -443,12 +443,13 @@ def test_orthogonalize_chol_blocked(gpu_ctx, m):
     assert ok.value == 0
 
 
-def test_sytrd_beyond_one_batch_of_partials(gpu_ctx):
-    """n = 10600: more row blocks (166 > 160) and dot chunks (42 > 40) than one load batch of the advance
-    kernel holds, so its continuation loops run; checked against rocSOLVER's ssytrd (same conventions)."""
+@pytest.mark.parametrize("n", [10600, 13000])
+def test_sytrd_beyond_one_batch_of_partials(gpu_ctx, n):
+    """n = 10600: more row blocks (166 > 160), dot chunks (42 > 40) and partial norms (332 > 320) than one load batch
+    of the advance / symv kernels holds, so their continuation loops run; n = 13000 adds the row-chunk partials
+    (26 > 24).  Checked against rocSOLVER's ssytrd (same conventions)."""
     torch = _t()
     ctx = gpu_ctx
-    n = 10600
     g = torch.Generator(device=ctx.device).manual_seed(5)
     X = torch.randn((n, n + 500), device=ctx.device, generator=g)
     S = (X @ X.T) / n
