@@ -32,7 +32,7 @@ import scipy.sparse
 from scipy.sparse import coo_matrix
 
 from . import grid
-from ._lib import Context, ptr, PMDLibraryError, c_p, c_i, C
+from ._lib import Context, ptr, PMDLibraryError, c_i, C
 from .pmdarray import PMDArray
 from .parallel import Dist, tile_partition
 
