@@ -226,7 +226,7 @@ def _compare_full(ctx, mov, block, frame_range, **kw):
     np.random.seed(7)
     pmd, diag = localmd_amd.localmd_decomposition(mov, block, frame_range, seed=seed, return_diagnostics=True, ctx=ctx, **kw)
     np.random.seed(7)
-    okw = {k: v for k, v in kw.items() if k not in ("sim_iters",)}
+    okw = {k: v for k, v in kw.items() if k not in ("sim_iters", "thresholds")}
     ref = O.localmd_decomposition(mov, block, frame_range, rng=DeviceSource(ctx, seed),
                                   thresholds=diag["thresholds"], **okw)
     return pmd, diag, ref
@@ -570,3 +570,53 @@ def test_pmdarray_device_expansion_matches_host(gpu_ctx):
         pmd.to_host()
     assert pmd._dev is None
     np.testing.assert_array_equal(pmd[5], host[1])
+
+
+def _check_structure_and_fit(pmd, diag, ref, mov):
+    """For inputs whose kept noise component is an arbitrary vector of a nearly degenerate noise subspace (very short
+    movies): everything that is well posed - tile ranks, CSR structure, statistics images, orthonormality, and how
+    well each side reconstructs the standardised movie on random probes."""
+    T, d1, d2 = mov.shape
+    np.testing.assert_array_equal(diag["tile_ranks"], ref.diag["tile_ranks"])
+    np.testing.assert_array_equal(pmd.u.indptr, ref.u.indptr)
+    np.testing.assert_array_equal(pmd.u.indices, ref.u.indices)
+    np.testing.assert_allclose(pmd.mean_img, ref.mean_img, rtol=1e-5)
+    np.testing.assert_allclose(pmd.var_img, ref.std_img, rtol=2e-4)
+    ur, ur_ref = pmd.u @ pmd.r, ref.u @ ref.r
+    assert np.abs(ur.T @ ur - np.eye(ur.shape[1])).max() < 2e-3
+    assert np.abs(pmd.v @ pmd.v.T - np.eye(pmd.v.shape[0])).max() < 2e-3
+    n = min(len(pmd.s), len(ref.s))
+    np.testing.assert_allclose(pmd.s[:2], ref.s[:2], rtol=2e-3)   # the signal part of the spectrum
+    rng = np.random.default_rng(0)
+    pi = rng.integers(0, d1 * d2, 600)
+    pt = rng.integers(0, T, 600)
+    y = ((mov - ref.mean_img[None]) / ref.std_img[None]).reshape(T, -1, order="F")[pt, pi]
+    rec = np.einsum("pk,k,kp->p", ur[pi], pmd.s, pmd.v[:, pt])
+    rec_ref = np.einsum("pk,k,kp->p", ur_ref[pi], ref.s, ref.v[:, pt])
+    e_hip, e_ref = np.mean((rec - y) ** 2), np.mean((rec_ref - y) ** 2)
+    assert abs(e_hip - e_ref) < 0.1 * e_ref + 1e-6, (e_hip, e_ref)
+    return n
+
+
+def test_full_pipeline_short_movie_and_single_tile(gpu_ctx):
+    """Edge cases of the reference's argument handling: fewer than 256 frames (no Welch chunk: the noise image is
+    all ones, pmd_loader.py:213-226), max_components larger than frames // temporal_avg_factor (capped with a
+    warning, decomposition.py:764-770), a field of view that is exactly one tile, and temporal_avg_factor >= frames
+    (ValueError, :762)."""
+    import localmd_amd
+
+    # With 20 temporal bins per tile the noise components (nearly equal singular values: their vectors are an arbitrary
+    # rotation of the noise subspace in either implementation) have roughness statistics that straddle simulated
+    # thresholds; injected thresholds between the signal and the noise statistics keep the rank decisions well posed.
+    thr = (1.35, 1.8)
+    mov = _movie(200, 20, 24, seed=41)
+    pmd, diag, ref = _compare_full(gpu_ctx, mov, (10, 12), 200, max_components=50, background_rank=1, thresholds=thr)
+    assert diag["max_components"] == 20 and np.all(pmd.var_img == 1.0)
+    _check_structure_and_fit(pmd, diag, ref, mov)
+    one = _movie(300, 10, 12, seed=42)
+    pmd1, diag1, ref1 = _compare_full(gpu_ctx, one, (10, 12), 300, max_components=4, background_rank=0, thresholds=thr)
+    assert len(diag1["tile_ranks"]) == 1
+    _check_structure_and_fit(pmd1, diag1, ref1, one)
+    with pytest.raises(ValueError):
+        localmd_amd.localmd_decomposition(mov, (10, 12), 200, temporal_avg_factor=200, ctx=gpu_ctx, seed=1,
+                                          thresholds=(1.0, 1.0))
