@@ -644,3 +644,27 @@ def test_full_pipeline_extreme_arguments(gpu_ctx, case):
         _check_full(pmd, diag, ref, mov, vt_tol=5e-3, orth_tol=1e-2, s_tol=3e-3, vt_tol_signal=2e-3)
     else:
         _check_full(pmd, diag, ref, mov, vt_tol=3e-3)
+
+
+def test_tiff_dataset_end_to_end(gpu_ctx, tmp_path):
+    """The dataset contract (dataset.py:38-114: shape + obj[list of frames]) through the TIFF reader: a uint16
+    multipage file decomposes to exactly what the same frames give as an in-memory array, in small frame batches."""
+    import localmd_amd
+    from localmd_amd import decomposition as Dm
+    from localmd_amd._minitiff import write_tiff
+
+    Dm.QUIET = True
+    mov = np.clip(_movie(420, 40, 30, seed=51) * 4.0 + 200.0, 0, 65535).astype(np.uint16)
+    fn = str(tmp_path / "movie.tif")
+    write_tiff(fn, mov)
+    kw = dict(max_components=5, background_rank=2, seed=3, thresholds=(1.2, 1.9), ctx=gpu_ctx)
+    np.random.seed(5)
+    a = localmd_amd.localmd_decomposition(localmd_amd.TiffArray(fn), (20, 10), 420, frame_batch_size=64, **kw)
+    np.random.seed(5)
+    b = localmd_amd.localmd_decomposition(mov.astype(np.float32), (20, 10), 420, **kw)
+    np.testing.assert_array_equal(a.u.indices, b.u.indices)
+    np.testing.assert_array_equal(a.u.data, b.u.data)
+    np.testing.assert_array_equal(a.s, b.s)
+    np.testing.assert_array_equal(a.v, b.v)
+    np.testing.assert_array_equal(a.mean_img, b.mean_img)
+    assert a.shape == (420, 40, 30) and a[7].shape == (40, 30)
