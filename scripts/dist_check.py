@@ -24,6 +24,10 @@ cases = [
           pixel_weighting=(0.5 + np.random.default_rng(1).random((44, 60))).astype(np.float32))),
     # several temporal windows (residual fitting on the later ones)
     ("windows", make_movie(900, 40, 44, seed=6), (20, 20), dict(frame_range=600, window_chunks=200, max_components=8, background_rank=2)),
+    # denoiser hooks (every rank applies them to its own tiles) and rank_prune (the random projection is keyed by the seed)
+    ("hooks", make_movie(500, 40, 50, seed=9), (20, 20), dict(max_components=6, background_rank=2,
+                                                              temporal_denoiser=lambda v: 0.5 * v + 0.25 * (v.roll(1, -1) + v.roll(-1, -1)))),
+    ("rank_prune", make_movie(300, 60, 60, seed=10), (10, 10), dict(max_components=8, background_rank=2, rank_prune=True)),
 ]
 for name, mov, blk, kw in cases:
     kw = dict(kw)
