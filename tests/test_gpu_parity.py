@@ -542,9 +542,10 @@ def test_denoiser_hooks_batched_and_first_window_only(gpu_ctx):
         localmd_amd.localmd_decomposition(mov, (20, 20), 800, spatial_denoiser="median", **kw)
 
 
-def test_pmdarray_device_expansion_matches_host(gpu_ctx):
+@pytest.mark.parametrize("order", ["F", "C"])
+def test_pmdarray_device_expansion_matches_host(gpu_ctx, order):
     """PMDArray.to_device(): __getitem__ on the GPU returns what the reference's SciPy / NumPy expansion
-    (pmdarray.py:132-171) returns, for every kind of key."""
+    (pmdarray.py:132-171) returns, for every kind of key and both pixel orders."""
     import localmd_amd
     from localmd_amd import decomposition as Dm
 
@@ -552,7 +553,7 @@ def test_pmdarray_device_expansion_matches_host(gpu_ctx):
     mov = _movie(600, 40, 50, seed=31)
     np.random.seed(1)
     pmd = localmd_amd.localmd_decomposition(mov, (20, 20), 600, max_components=6, background_rank=2, seed=9, sim_iters=8,
-                                            ctx=gpu_ctx)
+                                            ctx=gpu_ctx, order=order)
     keys = [
         (slice(None),), (5,), (slice(10, 300, 7),), ([3, 1, 599, 1],), (slice(0, 64), slice(4, 30), slice(7, 50)),
         (slice(None), 7, 9), (17, slice(None), slice(None)), (slice(100, 420), [1, 5, 9], [2, 2, 40]),
