@@ -669,3 +669,38 @@ def test_tiff_dataset_end_to_end(gpu_ctx, tmp_path):
     np.testing.assert_array_equal(a.v, b.v)
     np.testing.assert_array_equal(a.mean_img, b.mean_img)
     assert a.shape == (420, 40, 30) and a[7].shape == (40, 30)
+
+
+def test_public_svd_helpers_match_oracle():
+    """localmd_amd.projected_svd / compute_lowrank_factorized_svd (the reference's two other public entry points,
+    decomposition.py:936-1060) on the device against the oracle: both branches of each."""
+    import scipy.sparse
+    import localmd_amd
+
+    rng = np.random.default_rng(4)
+    # projected_svd: fewer rows than columns, then fewer columns than rows
+    p = np.linalg.qr(rng.standard_normal((40, 12)))[0].astype(np.float32)
+    v = (rng.standard_normal((12, 90)) * np.linspace(10, 1, 12)[:, None]).astype(np.float32)
+    for pp, vv in ((p, v), (rng.standard_normal((7, 90)).astype(np.float32), v.T.copy())):
+        r, s, vt = localmd_amd.projected_svd(pp, vv)
+        r0, s0, vt0 = O.projected_svd(pp, vv)
+        assert r.shape == r0.shape and s.shape == s0.shape and vt.shape == vt0.shape
+        np.testing.assert_allclose(s, s0, rtol=2e-4, atol=2e-4 * s0.max())
+        np.testing.assert_allclose((r * s) @ vt, pp @ vv, atol=1e-3 * np.abs(pp @ vv).max())
+        k = min(6, len(s0))
+        va = sign_align(vt[:k], vt0[:k], axis=1)
+        assert np.abs(va - vt0[:k]).max() < 2e-3
+    # compute_lowrank_factorized_svd: R <= frames (identity right matrix) and R > frames (right matrix = v)
+    u = scipy.sparse.random(300, 20, density=0.2, random_state=1, format="coo")
+    for ncol in (50, 8):
+        vm = rng.standard_normal((20, ncol)).astype(np.float32)
+        pl = localmd_amd.compute_lowrank_factorized_svd(u, vm, only_left=True)
+        p0 = O.compute_lowrank_factorized_svd(u, vm, only_left=True)
+        assert pl.shape == p0.shape
+        up = u @ pl
+        assert np.abs(up.T @ up - np.eye(pl.shape[1])).max() < 2e-3
+        rr, ss, vvt = localmd_amd.compute_lowrank_factorized_svd(u, vm, only_left=False)
+        r0, s0, vt0 = O.compute_lowrank_factorized_svd(u, vm, only_left=False)
+        np.testing.assert_allclose(ss, s0, rtol=5e-4, atol=5e-4 * s0.max())
+        full, full0 = (u @ rr) * ss @ vvt, (u @ r0) * s0 @ vt0
+        np.testing.assert_allclose(full, full0, atol=2e-3 * np.abs(full0).max())
