@@ -8,8 +8,12 @@ imports it.
 PARITY UNPINNED: the reference (apasarkar/localmd @ 2025-01-31) cannot be executed in the
 build container (``import localmd`` -> ModuleNotFoundError: jax; no network), its tests
 assert no numerical result and it ships no golden vectors (SURVEY.md sections 4, 8(c)).
-This file therefore restates the reference line by line in NumPy/SciPy -- fp32 where JAX
-computes in fp32, the same LAPACK family (sgeqrf/sorgqr, sgesdd, ssyevd) -- and is pinned
+This file therefore restates the reference line by line in NumPy/SciPy -- arrays and products
+in fp32 where JAX computes in fp32, factorisations through numpy.linalg (the geqrf/orgqr, gesdd,
+syevd family; NB numpy.linalg computes them in DOUBLE for float32 input and rounds the results to
+float32 (numpy/linalg/_linalg.py, _commonType), so these steps are the exact-arithmetic limit of
+the reference's fp32 LAPACK calls, not a bit-for-bit model of their rounding; measured in
+scripts/eig_accuracy_probe.py) -- and is pinned
 only by (a) closed-form known-answer tests (tests/test_oracle_known_answers.py),
 (b) scipy.signal.welch as an independent implementation of the Welch semantics that
 jax.scipy.signal.welch mirrors.  Third-party semantics restated here: jax/jaxlib
