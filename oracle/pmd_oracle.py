@@ -36,6 +36,34 @@ from . import philox
 
 F32 = np.float32
 VERBOSE = False
+# "double": numpy.linalg (computes in double for float32 input, rounds the result) - the default referee.
+# "single": scipy.linalg on float32 arrays (true sgeqrf/sorgqr, sgesdd, ssyevd), the precision jaxlib's CPU LAPACK
+# kernels run in for the reference's float32 arrays.
+LAPACK_PRECISION = "double"
+
+
+def _qr(a):
+    if LAPACK_PRECISION == "single" and a.dtype == np.float32:
+        import scipy.linalg
+
+        return scipy.linalg.qr(a, mode="economic", check_finite=False)
+    return np.linalg.qr(a)
+
+
+def _svd(a):
+    if LAPACK_PRECISION == "single" and a.dtype == np.float32:
+        import scipy.linalg
+
+        return scipy.linalg.svd(a, full_matrices=False, check_finite=False, lapack_driver="gesdd")
+    return np.linalg.svd(a, full_matrices=False)
+
+
+def _eigh(a):
+    if LAPACK_PRECISION == "single" and a.dtype == np.float32:
+        import scipy.linalg
+
+        return scipy.linalg.eigh(a, check_finite=False, driver="evd")
+    return np.linalg.eigh(a)
 
 
 def display(msg):
@@ -54,7 +82,7 @@ def svd_hermitian(a: np.ndarray):
     """jnp.linalg.svd(a, hermitian=True): eigh -> sort by |w| descending -> u = v*sign(w).
 
     Used at decomposition.py:984, :1090, :1129.  Returns (u, s, vh)."""
-    w, v = np.linalg.eigh(a)
+    w, v = _eigh(a)
     s = np.abs(w)
     idx = np.argsort(s, kind="stable")[::-1]
     s = s[idx]
@@ -223,9 +251,9 @@ def truncated_random_svd(input_matrix: np.ndarray, random_data: np.ndarray, rank
     """decomposition.py:59-73.  random_data is the injected (t, rank+10) Gaussian matrix."""
     a = input_matrix.astype(F32, copy=False)
     projected = a @ random_data.astype(F32, copy=False)
-    q, _ = np.linalg.qr(projected)
+    q, _ = _qr(projected)
     b = q.T @ a
-    u, s, v = np.linalg.svd(b, full_matrices=False)
+    u, s, v = _svd(b)
     u_final = q @ u
     return u_final[:, :rank], s[:rank], v[:rank, :]
 
@@ -234,9 +262,9 @@ def loader_truncated_random_svd(input_matrix, random_data, rank: int):
     """pmd_loader.py:46-68 (returns U and s*V)."""
     a = input_matrix.astype(F32, copy=False)
     projected = a @ random_data.astype(F32, copy=False)
-    q, _ = np.linalg.qr(projected)
+    q, _ = _qr(projected)
     b = q.T @ a
-    u, s, v = np.linalg.svd(b, full_matrices=False)
+    u, s, v = _svd(b)
     u_final = q @ u
     v = s[:, None] * v
     return u_final[:, :rank], v[:rank, :]
@@ -297,7 +325,7 @@ def single_block_md(block, random_data, rank, temporal_avg_factor, spatial_avera
     v_ds = u_mat_downsample.T @ np.reshape(block_downsample, (d1n * d2n, t), order=order)
     if temporal_denoiser is not None:
         v_ds = temporal_denoiser(v_ds)
-    v_mat_basis = np.linalg.svd(v_ds, full_matrices=False)[2]
+    v_mat_basis = _svd(v_ds)[2]
 
     block_2d = np.reshape(block, (d1 * d2, t), order=order)
     spf = block_2d @ v_mat_basis.T
@@ -306,9 +334,9 @@ def single_block_md(block, random_data, rank, temporal_avg_factor, spatial_avera
         spf = spatial_denoiser(spf)
         spf = spf.transpose(1, 2, 0).reshape((d1 * d2, v_mat_basis.shape[0]), order=order)
 
-    u_final, _, _ = np.linalg.svd(spf, full_matrices=False)
+    u_final, _, _ = _svd(spf)
     v_new = u_final.T @ block_2d
-    v_left, v_sing, v_right = np.linalg.svd(v_new, full_matrices=False)
+    v_left, v_sing, v_right = _svd(v_new)
     u_final = u_final @ v_left
     v_final = v_sing[:, None] * v_right
     u_final = np.reshape(u_final, (d1, d2, u_final.shape[1]), order=order)

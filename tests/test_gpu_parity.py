@@ -704,3 +704,18 @@ def test_public_svd_helpers_match_oracle():
         np.testing.assert_allclose(ss, s0, rtol=5e-4, atol=5e-4 * s0.max())
         full, full0 = (u @ rr) * ss @ vvt, (u @ r0) * s0 @ vt0
         np.testing.assert_allclose(full, full0, atol=2e-3 * np.abs(full0).max())
+
+
+@pytest.mark.parametrize("case", [
+    dict(T=600, d1=40, d2=50, block=(20, 20), frames=600, kw=dict(max_components=6, background_rank=2)),
+    dict(T=900, d1=36, d2=44, block=(16, 20), frames=300, kw=dict(max_components=5, background_rank=0)),
+    dict(T=640, d1=64, d2=64, block=(32, 32), frames=640, kw=dict(max_components=12, background_rank=4, temporal_avg_factor=8)),
+])
+def test_full_pipeline_against_single_precision_lapack_oracle(gpu_ctx, case, monkeypatch):
+    """The same comparison with the oracle's QR / SVD / eigh in true single precision (scipy.linalg s-routines, the
+    precision of jaxlib's CPU kernels for the reference's float32 arrays) instead of numpy.linalg's double: the
+    tolerances of the default comparison still hold."""
+    monkeypatch.setattr(O, "LAPACK_PRECISION", "single")
+    mov = _movie(case["T"], case["d1"], case["d2"], seed=case["T"] // 3)
+    pmd, diag, ref = _compare_full(gpu_ctx, mov, case["block"], case["frames"], sim_iters=8, **case["kw"])
+    _check_full(pmd, diag, ref, mov, vt_tol=3e-3)
