@@ -28,7 +28,10 @@ for n, T, ratio in ((89, 314, 66.0), (300, 1000, 100.0), (1200, 3000, 100.0)):
     G64 = G32.astype(np.float64)   # the matrix every solver is given
     print(f"n={n} T={T} sigma ratio {ratio}")
     w, E = np.linalg.eigh(G32)
-    report("numpy float32 eigh (LAPACK)", G64, V, w, E)
+    report("numpy.linalg (double inside)", G64, V, w, E)
+    import scipy.linalg
+    w, E = scipy.linalg.eigh(G32, driver="evd", check_finite=False)
+    report("scipy float32 ssyevd", G64, V, w, E)
     ctx = _lib.Context(0); P = _lib.ptr
     for mode in ("rocsolver", "own"):
         os.environ["PMD_SYEVD"] = mode
