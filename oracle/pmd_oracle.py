@@ -39,7 +39,7 @@ VERBOSE = False
 # "double": numpy.linalg (computes in double for float32 input, rounds the result) - the default referee.
 # "single": scipy.linalg on float32 arrays (true sgeqrf/sorgqr, sgesdd, ssyevd), the precision jaxlib's CPU LAPACK
 # kernels run in for the reference's float32 arrays.
-LAPACK_PRECISION = "double"
+LAPACK_PRECISION = "single" if __import__("os").environ.get("ORACLE_LAPACK", "") == "single" else "double"
 
 
 def _qr(a):
