@@ -145,6 +145,11 @@ int pmd_compact_rows(pmd_ctx* ctx, const float* Out, long ldo, const int* col_of
 int pmd_gram_u(pmd_ctx* ctx, const float* Uw, int dpad, int b1, int b2, const int* tile_pix, const int* pairs,
                int n_pairs, const int* origins, const int* col_off, const int* ranks, int n_tiles, int Rt,
                const float* basis, long D, int K, float* G, long ldg);
+/* Which eigen-directions pmd_orthogonalize / pmd_orthogonalize_factored keep.  rel_cutoff < 0 (default): the
+ * reference's rule - jnp.linalg.svd(hermitian=True) returns |lambda| and u = v sign(lambda), so `eig_vals > 0`
+ * (decomposition.py:988) keeps every direction whose eigenvalue is not exactly zero, numerically null ones included.
+ * rel_cutoff >= 0: keep lambda > rel_cutoff * lambda_max only ("expose a relative cutoff option"). */
+int pmd_ctx_set_null_cutoff(pmd_ctx* ctx, float rel_cutoff);
 /* A15: P with (U P)^T (U P) = I (decomposition.py:976-999, only_left=True).  M = right matrix
  * (R x m, NULL = identity, then m = R).  G is overwritten.  *rprime_host = columns kept. */
 size_t pmd_orthogonalize_workspace_bytes(int R, int m, int has_m);
@@ -165,7 +170,8 @@ int pmd_gram_apply(pmd_ctx* ctx, const float* Gblk, const float* Gbg, const floa
                    const int* nbr, const int* col_off, const int* ranks, int n_tiles, int Rt, int K, int max_rank,
                    const float* M, long ldm, int ncols, float* GM, long ldgm);
 /* A15/A16/A17 with P = M E^T kept factored (R > frames): Et rows = eigenvectors of M^T G M / sqrt(lambda)
- * (lambda > 0, |lambda| descending); then V = Et (M^T Z), its SVD, and R_out = M (Et^T W). */
+ * (|lambda| descending; which directions are kept: pmd_ctx_set_null_cutoff); then V = Et (M^T Z), its SVD, and
+ * R_out = M (Et^T W). */
 size_t pmd_orthogonalize_factored_workspace_bytes(int m);
 int pmd_orthogonalize_factored(pmd_ctx* ctx, const float* M, int Rc, int m, long ldm, const float* GM, long ldgm,
                                float* Et_out, long lde, int* rprime_host, void* ws, size_t ws_bytes);
@@ -190,7 +196,10 @@ size_t pmd_gram_mtgm_workspace_bytes(int rows, int m);
 int pmd_gram_mtgm(pmd_ctx* ctx, const float* M, int rows, int m, long ldm, const float* GM, long ldgm, float* C, long ldc,
                   void* ws, size_t ws_bytes);
 size_t pmd_chol_inverse_workspace_bytes(int m);
-int pmd_chol_inverse(pmd_ctx* ctx, float* C, int m, long ldc, int* ok_host, void* ws, size_t ws_bytes);
+/* abs_last_pivot != 0: the caller has rotated a known null direction of C into the last row / column; a negative last
+ * pivot is then replaced by its absolute value instead of failing - the Cholesky-route form of the reference keeping
+ * numerically null directions through |lambda| (svd(hermitian=True) at decomposition.py:984, `eig_vals > 0` at :988). */
+int pmd_chol_inverse(pmd_ctx* ctx, float* C, int m, long ldc, int abs_last_pivot, int* ok_host, void* ws, size_t ws_bytes);
 /* dst (cols x rows, ld_dst) = src (rows x cols, ld_src)^T, row-major */
 int pmd_transpose(pmd_ctx* ctx, const float* src, long ld_src, int rows, int cols, float* dst, long ld_dst);
 /* A13/A14: CSR arrays of the sparse spatial matrix built on the device (decomposition.py:812-853, :929-930);

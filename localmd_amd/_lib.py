@@ -70,7 +70,8 @@ SIGNATURES = {
     "pmd_gram_mtgm_workspace_bytes": (c_sz, [c_i, c_i]),
     "pmd_gram_mtgm": (c_i, [c_p, c_p, c_i, c_i, c_l, c_p, c_l, c_p, c_l, c_p, c_sz]),
     "pmd_chol_inverse_workspace_bytes": (c_sz, [c_i]),
-    "pmd_chol_inverse": (c_i, [c_p, c_p, c_i, c_l, C.POINTER(c_i), c_p, c_sz]),
+    "pmd_chol_inverse": (c_i, [c_p, c_p, c_i, c_l, c_i, C.POINTER(c_i), c_p, c_sz]),
+    "pmd_ctx_set_null_cutoff": (c_i, [c_p, C.c_float]),
     "pmd_transpose": (c_i, [c_p, c_p, c_l, c_i, c_i, c_p, c_l]),
     "pmd_csr_count": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_p]),
     "pmd_csr_fill": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_i,

@@ -34,6 +34,7 @@ int pmd_ctx_create(int device, void* hip_stream, pmd_ctx** out) {
   ctx->blas = nullptr;
   ctx->err[0] = 0;
   ctx->profile = false;
+  ctx->null_cutoff = -1.f;
   ctx->atx_label = nullptr;
   if (rocblas_create_handle(&ctx->blas) != rocblas_status_success) { delete ctx; return PMD_ERR_BLAS; }
   rocblas_set_stream(ctx->blas, ctx->stream);
@@ -51,6 +52,12 @@ int pmd_ctx_destroy(pmd_ctx* ctx) {
   if (ctx->split_ws) hipFree(ctx->split_ws);
   if (ctx->blas) rocblas_destroy_handle(ctx->blas);
   delete ctx;
+  return PMD_OK;
+}
+
+int pmd_ctx_set_null_cutoff(pmd_ctx* ctx, float rel_cutoff) {
+  CTX_CHECK(ctx);
+  ctx->null_cutoff = rel_cutoff;
   return PMD_OK;
 }
 
@@ -325,9 +332,9 @@ int pmd_gram_mtgm(pmd_ctx* ctx, const float* M, int rows, int m, long ldm, const
   return pmd_gram_mtgm_impl(ctx, M, rows, m, ldm, GM, ldgm, C, ldc, ws, ws_bytes);
 }
 size_t pmd_chol_inverse_workspace_bytes(int m) { return pmd_chol_inverse_workspace_bytes_impl(m); }
-int pmd_chol_inverse(pmd_ctx* ctx, float* C, int m, long ldc, int* ok_host, void* ws, size_t ws_bytes) {
+int pmd_chol_inverse(pmd_ctx* ctx, float* C, int m, long ldc, int abs_last_pivot, int* ok_host, void* ws, size_t ws_bytes) {
   CTX_CHECK(ctx);
-  return pmd_chol_inverse_impl(ctx, C, m, ldc, ok_host, ws, ws_bytes);
+  return pmd_chol_inverse_impl(ctx, C, m, ldc, abs_last_pivot, ok_host, ws, ws_bytes);
 }
 int pmd_transpose(pmd_ctx* ctx, const float* src, long ld_src, int rows, int cols, float* dst, long ld_dst) {
   CTX_CHECK(ctx);

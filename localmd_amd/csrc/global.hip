@@ -373,17 +373,24 @@ int pmd_orthogonalize_impl(pmd_ctx* ctx, float* G, int R, const float* M, int m,
   PMD_HIP(ctx, hipMemcpyAsync(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   PMD_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (hinfo != 0) return pmd_fail(ctx, PMD_ERR_BLAS, "rocsolver_ssyevd", "did not converge");
-  // jnp.linalg.svd(hermitian=True): sort by |lambda| descending, then keep lambda > 0
+  // jnp.linalg.svd(hermitian=True): sort by |lambda| descending
   std::vector<int> idx(m);
   for (int i = 0; i < m; ++i) idx[i] = i;
   std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return std::fabs(hw[a]) > std::fabs(hw[b]); });
   std::vector<int> hperm;
   std::vector<float> hscale;
-  for (int i = 0; i < m; ++i)
-    if (hw[idx[i]] > 0.f) {
+  // jnp.linalg.svd(hermitian=True) returns |lambda| and u = v sign(lambda): `eig_vals > 0` (decomposition.py:988)
+  // keeps every direction whose eigenvalue is not exactly zero.  null_cutoff >= 0 (pmd_ctx_set_null_cutoff):
+  // only lambda > cutoff * lambda_max.
+  const float lmax = m > 0 ? std::fabs(hw[idx[0]]) : 0.f;
+  for (int i = 0; i < m; ++i) {
+    const float lam = hw[idx[i]];
+    const bool keep = ctx->null_cutoff < 0.f ? (lam != 0.f && lam == lam) : (lam > ctx->null_cutoff * lmax);
+    if (keep) {
       hperm.push_back(idx[i]);
-      hscale.push_back(1.0f / std::sqrt(hw[idx[i]]));
+      hscale.push_back((lam < 0.f ? -1.0f : 1.0f) / std::sqrt(std::fabs(lam)));
     }
+  }
   const int rp = (int)hperm.size();
   *rprime_out = rp;
   if (rp == 0) return PMD_OK;
@@ -948,11 +955,18 @@ int pmd_orthogonalize_factored_impl(pmd_ctx* ctx, const float* M, int Rc, int m,
   std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return std::fabs(hw[a]) > std::fabs(hw[b]); });
   std::vector<int> hperm;
   std::vector<float> hscale;
-  for (int i = 0; i < m; ++i)
-    if (hw[idx[i]] > 0.f) {
+  // jnp.linalg.svd(hermitian=True) returns |lambda| and u = v sign(lambda): `eig_vals > 0` (decomposition.py:988)
+  // keeps every direction whose eigenvalue is not exactly zero.  null_cutoff >= 0 (pmd_ctx_set_null_cutoff):
+  // only lambda > cutoff * lambda_max.
+  const float lmax = m > 0 ? std::fabs(hw[idx[0]]) : 0.f;
+  for (int i = 0; i < m; ++i) {
+    const float lam = hw[idx[i]];
+    const bool keep = ctx->null_cutoff < 0.f ? (lam != 0.f && lam == lam) : (lam > ctx->null_cutoff * lmax);
+    if (keep) {
       hperm.push_back(idx[i]);
-      hscale.push_back(1.0f / std::sqrt(hw[idx[i]]));
+      hscale.push_back((lam < 0.f ? -1.0f : 1.0f) / std::sqrt(std::fabs(lam)));
     }
+  }
   const int rp = (int)hperm.size();
   *rprime_out = rp;
   if (rp == 0) return PMD_OK;
@@ -1031,7 +1045,10 @@ int pmd_projected_svd_factored_impl(pmd_ctx* ctx, const float* M, int Rc, int m,
 // registers for the whole factorisation, only the pivot column travels through LDS (one barrier per step).
 // *info = 1-based global index of the first non-positive pivot (left untouched otherwise).
 #define CHOL_NB 128
-__global__ __launch_bounds__(256) void potf2_block_kernel(float* __restrict__ A, long ld, int nb, int k0, int* __restrict__ info) {
+// n_abs_last > 0: a negative pivot number n_abs_last (1-based, the LAST pivot of the whole matrix) is replaced by its
+// absolute value - the Cholesky-route form of the reference keeping a numerically null direction through |lambda|.
+__global__ __launch_bounds__(256) void potf2_block_kernel(float* __restrict__ A, long ld, int nb, int k0, int* __restrict__ info,
+                                                          int n_abs_last) {
   __shared__ float s_col[2][CHOL_NB];
   const int tid = threadIdx.x;
   const int tr = tid >> 4, tc = tid & 15;
@@ -1061,10 +1078,14 @@ __global__ __launch_bounds__(256) void potf2_block_kernel(float* __restrict__ A,
       }
     }
     __syncthreads();
-    const float piv = col[k];
+    float piv = col[k];
     if (!(piv > 0.f)) {
-      bad = k0 + k + 1;
-      break;  // uniform: every thread reads the same pivot
+      if (k0 + k + 1 == n_abs_last && piv < 0.f) {
+        piv = -piv;
+      } else {
+        bad = k0 + k + 1;
+        break;  // uniform: every thread reads the same pivot
+      }
     }
     const float dk = sqrtf(piv);
     const float inv = 1.f / dk;
@@ -1107,7 +1128,7 @@ __global__ __launch_bounds__(256) void potf2_block_kernel(float* __restrict__ A,
 // diagonal block in LDS, panel by rocBLAS strsm, trailing update by ssyrk.  rocSOLVER's spotrf spends half
 // of its 35 ms at n = 10^4 in its unblocked diagonal-block kernel.
 // tmp: n x CHOL_NB floats (the panel before it is copied back), linv: CHOL_NB x CHOL_NB floats
-static int chol_lower_rm(pmd_ctx* ctx, int n, float* A, long ld, int* info, float* tmp, float* linv) {
+static int chol_lower_rm(pmd_ctx* ctx, int n, float* A, long ld, int* info, float* tmp, float* linv, int abs_last_pivot) {
   pmd_prof_scope prof__(ctx, "cholesky");
   PMD_HIP(ctx, hipMemsetAsync(info, 0, sizeof(int), ctx->stream));
   PMD_HIP(ctx, hipMemsetAsync(linv, 0, sizeof(float) * CHOL_NB * CHOL_NB, ctx->stream));
@@ -1115,7 +1136,7 @@ static int chol_lower_rm(pmd_ctx* ctx, int n, float* A, long ld, int* info, floa
   for (int k0 = 0; k0 < n; k0 += CHOL_NB) {
     const int nb = std::min(CHOL_NB, n - k0);
     float* D = A + (long)k0 * ld + k0;
-    hipLaunchKernelGGL(potf2_block_kernel, dim3(1), dim3(256), 0, ctx->stream, D, ld, nb, k0, info);
+    hipLaunchKernelGGL(potf2_block_kernel, dim3(1), dim3(256), 0, ctx->stream, D, ld, nb, k0, info, abs_last_pivot ? n : -1);
     PMD_LAUNCH_CHECK(ctx, "potf2_block_kernel");
     const int rest = n - k0 - nb;
     if (rest <= 0) break;
@@ -1168,7 +1189,7 @@ int pmd_gram_mtgm_impl(pmd_ctx* ctx, const float* M, int rows, int m, long ldm, 
 // In place: C = U_c^T U_c (row-major lower triangle read) -> Et = U_c^{-T} (row-major lower, rest zeroed).
 size_t pmd_chol_inverse_workspace_bytes_impl(int m) { return ((size_t)m + CHOL_NB) * CHOL_NB * sizeof(float) + 8192; }
 
-int pmd_chol_inverse_impl(pmd_ctx* ctx, float* C, int m, long ldc, int* ok_host, void* ws, size_t ws_bytes) {
+int pmd_chol_inverse_impl(pmd_ctx* ctx, float* C, int m, long ldc, int abs_last_pivot, int* ok_host, void* ws, size_t ws_bytes) {
   pmd_arena ar(ws, ws_bytes);
   int* info = ar.take_n<int>(4);
   float* chol_tmp = ar.take_n<float>((size_t)m * CHOL_NB);
@@ -1178,11 +1199,11 @@ int pmd_chol_inverse_impl(pmd_ctx* ctx, float* C, int m, long ldc, int* ok_host,
   int hinfo = 0;
   {
     const char* cmode = getenv("PMD_CHOLESKY");
-    if (cmode && !strcmp(cmode, "rocsolver")) {
+    if (cmode && !strcmp(cmode, "rocsolver") && !abs_last_pivot) {
       pmd_prof_scope prof__(ctx, "rocsolver_spotrf");
       PMD_BLAS(ctx, rocsolver_spotrf(ctx->blas, rocblas_fill_upper, m, C, (rocblas_int)ldc, info));
     } else {
-      RUN(chol_lower_rm(ctx, m, C, ldc, info, chol_tmp, chol_linv));
+      RUN(chol_lower_rm(ctx, m, C, ldc, info, chol_tmp, chol_linv, abs_last_pivot));
     }
   }
   PMD_HIP(ctx, hipMemcpyAsync(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -1205,7 +1226,7 @@ int pmd_chol_inverse_impl(pmd_ctx* ctx, float* C, int m, long ldc, int* ok_host,
 int pmd_orthogonalize_chol_impl(pmd_ctx* ctx, const float* M, int Rc, int m, long ldm, const float* GM, long ldgm,
                                 float* Et_out, long lde, int* ok_host, void* ws, size_t ws_bytes) {
   RUN(pmd_gram_mtgm_impl(ctx, M, Rc, m, ldm, GM, ldgm, Et_out, lde, ws, ws_bytes));
-  return pmd_chol_inverse_impl(ctx, Et_out, m, lde, ok_host, ws, ws_bytes);
+  return pmd_chol_inverse_impl(ctx, Et_out, m, lde, 0, ok_host, ws, ws_bytes);
 }
 
 int pmd_transpose_impl(pmd_ctx* ctx, const float* src, long lds_, int rows, int cols, float* dst, long ldd) {

@@ -125,7 +125,7 @@ size_t pmd_gram_mtgm_workspace_bytes_impl(int rows, int m);
 int pmd_gram_mtgm_impl(pmd_ctx* ctx, const float* M, int rows, int m, long ldm, const float* GM, long ldgm, float* C,
                        long ldc, void* ws, size_t ws_bytes);
 size_t pmd_chol_inverse_workspace_bytes_impl(int m);
-int pmd_chol_inverse_impl(pmd_ctx* ctx, float* C, int m, long ldc, int* ok_host, void* ws, size_t ws_bytes);
+int pmd_chol_inverse_impl(pmd_ctx* ctx, float* C, int m, long ldc, int abs_last_pivot, int* ok_host, void* ws, size_t ws_bytes);
 int pmd_transpose_impl(pmd_ctx* ctx, const float* src, long lds_, int rows, int cols, float* dst, long ldd);
 int pmd_orthogonalize_chol_impl(pmd_ctx* ctx, const float* M, int Rc, int m, long ldm, const float* GM, long ldgm,
                                 float* Et_out, long lde, int* ok_host, void* ws, size_t ws_bytes);

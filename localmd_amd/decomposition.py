@@ -105,7 +105,9 @@ class _Movie:
             step = max(1, int(frame_batch_size))
             for t0 in range(0, self.T, step):
                 keys = list(range(t0, min(self.T, t0 + step)))
-                chunk = np.asarray(dataset_obj[keys], dtype=np.float32)[:, i_lo:i_hi, :].reshape(len(keys), self.D)
+                # lazy_data_loader.__getitem__ ends with .squeeze() (dataset.py:114): a one-frame batch comes back 2-D
+                chunk = np.asarray(dataset_obj[keys], dtype=np.float32).reshape(len(keys), self.d1, self.d2)
+                chunk = chunk[:, i_lo:i_hi, :].reshape(len(keys), self.D)
                 self.dev[t0 : t0 + len(keys)].copy_(torch.from_numpy(np.ascontiguousarray(chunk)))
         # one extra block of zero rows: kernels that walk the rows in 1024-blocks may start at any owned offset
         self.rows_alloc = _round_up(self.D, 1024) + 1024
@@ -327,6 +329,8 @@ def localmd_decomposition(
     thresholds=None,
     sim_iters: int = 250,
     orthogonalizer: str = "auto",
+    null_directions: str = "keep",
+    null_cutoff: float = 0.0,
     distributed: bool = False,
     return_diagnostics: bool = False,
     ctx: Optional[Context] = None,
@@ -341,6 +345,8 @@ def localmd_decomposition(
         raise ValueError("order must be 'F' or 'C'")
     if orthogonalizer not in ("auto", "eigh", "cholesky"):
         raise ValueError("orthogonalizer must be 'auto', 'eigh' or 'cholesky'")
+    if null_directions not in ("keep", "drop"):
+        raise ValueError("null_directions must be 'keep' (the reference's rule) or 'drop'")
     timings = {}
     t_start = time.perf_counter()
 
@@ -356,6 +362,9 @@ def localmd_decomposition(
         ctx = Context(0 if device is None else device)
     try:
         lib = ctx.lib
+        # decomposition.py:984-996 keeps every direction of the orthogonalising eigendecomposition whose eigenvalue is
+        # not exactly zero ("keep"); "drop" removes lambda <= null_cutoff * lambda_max and the known null direction
+        ctx.call("pmd_ctx_set_null_cutoff", -1.0 if null_directions == "keep" else float(null_cutoff))
         if seed is None:
             seed = int(np.random.randint(0, 2 ** 31 - 1))
         seed = int(seed) & 0xFFFFFFFFFFFFFFFF
@@ -676,6 +685,7 @@ def localmd_decomposition(
         if K > 0:
             vc[Rt:Rt + K, :] = pj_dev[:, :crop]
         right = vc
+        col_sigma = vc.norm(dim=1).cpu().numpy() if return_diagnostics else None   # norm of every trace (tile sigma)
         if rank_prune:
             if rank_prune_factor <= 0 or rank_prune_factor > 1:
                 raise ValueError("Rank prune factor should be a value in the interval (0, 1]")
@@ -757,10 +767,14 @@ def localmd_decomposition(
             chol_ok = False
             if orthogonalizer in ("auto", "cholesky"):
                 m_eff = m_cols
-                if all_frames and not rank_prune and pixel_weighting is None:
-                    # Every standardised trace sums to ~0 over the frames it was centred on, so the constant
-                    # vector is a numerically null right vector of v_cropped.  Rotate it into the last column
-                    # (Householder H, H e_m = 1/sqrt(m)) and drop that column: same column space of U right.
+                abs_last = 0
+                if all_frames and crop == T and not rank_prune and pixel_weighting is None:
+                    # Every standardised trace sums to ~0 over the frames it was centred on (all of them: crop == T),
+                    # so the constant vector is a numerically null right vector of v_cropped.  Rotate it into the
+                    # last column (Householder H, H e_m = 1/sqrt(m)): the leading block of C is then well
+                    # conditioned and the null direction sits in the last pivot.  "keep" (the reference's rule:
+                    # |lambda| of a numerically null direction is kept, decomposition.py:984-988): the last pivot
+                    # enters through its absolute value; "drop": the column is dropped (one component fewer).
                     nhat = np.full(m_cols, 1.0 / math.sqrt(m_cols))
                     hv = -nhat
                     hv[-1] += 1.0
@@ -769,7 +783,10 @@ def localmd_decomposition(
                     y_dev = torch.empty((Rc, 1), dtype=torch.float32, device=ctx.device)
                     ctx.call("pmd_gemm", 0, 0, Rc, 1, m_cols, 1.0, ptr(right), ld_right, ptr(hv_dev), 1, 0.0, ptr(y_dev), 1)
                     ctx.call("pmd_gemm", 0, 0, Rc, m_cols, 1, -2.0, ptr(y_dev), 1, ptr(hv_dev), m_cols, 1.0, ptr(right), ld_right)
-                    m_eff = m_cols - 1
+                    if null_directions == "keep":
+                        abs_last = 1
+                    else:
+                        m_eff = m_cols - 1
                 gram_apply(m_eff)
                 ok_c = c_i(0)
                 # C = right[rows]^T GM[rows] (summed over the ranks when the rows are sharded)
@@ -801,7 +818,7 @@ def localmd_decomposition(
                 sc.stream.wait_event(ev_c)
                 with torch.cuda.stream(sc.stream):
                     ws2 = sc.workspace(lib.pmd_chol_inverse_workspace_bytes(m_eff))
-                    sc.call("pmd_chol_inverse", ptr(Et_dev), m_eff, m_cols, C.byref(ok_c), ptr(ws2), ws2.numel())
+                    sc.call("pmd_chol_inverse", ptr(Et_dev), m_eff, m_cols, abs_last, C.byref(ok_c), ptr(ws2), ws2.numel())
                     ev_e = torch.cuda.Event()
                     ev_e.record(sc.stream)
                 main.wait_event(ev_e)
@@ -977,7 +994,7 @@ def localmd_decomposition(
             "tile_ut": ut_dev.cpu().numpy(), "origins": origins, "pix": pix_c, "block_weights": block_weights,
             "max_components": r, "rank_before": R, "rank_after": rp, "timings": timings,
             "orthogonalizer": ("cholesky" if (use_right and chol_ok) else "eigh"),
-            "crop": crop, "dpad": dpad, "v_proj": Vp.cpu().numpy(),
+            "crop": crop, "dpad": dpad, "v_proj": Vp.cpu().numpy(), "col_sigma": col_sigma, "n_tile_cols": Rt,
         }
         return final_movie, diag
     finally:

@@ -42,6 +42,24 @@ VERBOSE = False
 LAPACK_PRECISION = "single" if __import__("os").environ.get("ORACLE_LAPACK", "") == "single" else "double"
 
 
+class arbiter_precision:
+    """``with arbiter_precision():`` every array, product and factorisation of this module runs in float64 (pass
+    dtype="float64" to localmd_decomposition inside the block).  This is NOT the reference's arithmetic (fp32
+    throughout): it is the exact-arithmetic limit of the reference's ALGORITHM on the same inputs, used by the
+    tests to rank two fp32 implementations (the HIP path, this oracle in fp32) by their distance to it."""
+
+    def __enter__(self):
+        global F32
+        self._saved = F32
+        F32 = np.float64
+        return self
+
+    def __exit__(self, *exc):
+        global F32
+        F32 = self._saved
+        return False
+
+
 def _qr(a):
     if LAPACK_PRECISION == "single" and a.dtype == np.float32:
         import scipy.linalg

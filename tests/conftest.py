@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a HIP device (MI355X); run with -m gpu")
+    config.addinivalue_line("markers", "slow: minutes of CPU oracle work; runs only with PMD_RUN_SLOW=1")
 
 
 @pytest.fixture(scope="session")

@@ -1,0 +1,138 @@
+"""
+Bounded, seeded fuzz of the whole decomposition against the oracle (GPU): the random draws of round 1's
+`scripts/fuzz_parity.py 40 1`, restricted to a fixed list of cases that includes every case that run reported as failing its
+`s` comparison (2, 3, 9, 12, 19, 22, 27, 33; gpurun_out/fuzz1.log of round 1, analysed in profiles/r02_fuzz_explain.txt).
+
+What those failures were: the offending singular values are noise-level ones (sigma ~ 30-90 against sigma_1 ~ 600-900)
+carried by the components every tile KEEPS although they fail the roughness tests (evaluation.py:195-222) - arbitrary
+vectors of each tile's noise subspace, on which two fp32 implementations differ.  The decisive comparison, encoded
+here: the singular values of the data projected on the span of the PASSING tile components (computed in float64 from
+each side's own U) agree; so do the tile decisions, the CSR structure, U_data on the stable columns and the fit.
+"""
+import numpy as np
+import pytest
+
+from tests import parity_metrics as PM
+import tests.test_gpu_parity as tp
+
+pytestmark = pytest.mark.gpu
+
+FUZZ_SEED = 1
+FUZZ_CASES = [0, 2, 3, 5, 9, 12, 19, 22, 27, 33]
+
+
+def draw_cases(n_cases, seed=FUZZ_SEED):
+    """The exact draws of scripts/fuzz_parity.py (round 1)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for case in range(n_cases):
+        b1, b2 = (int(2 * rng.integers(5, 17)) for _ in range(2))
+        d1 = int(rng.integers(b1, 3 * b1 + 8))
+        d2 = int(rng.integers(b2, 3 * b2 + 8))
+        taf = int(rng.choice([1, 2, 4, 5, 10]))
+        T = int(rng.integers(300, 900))
+        frames = T if rng.random() < 0.6 else int(rng.integers(260, T))
+        kw = dict(max_components=int(rng.integers(2, 11)), background_rank=int(rng.integers(0, 6)), temporal_avg_factor=taf,
+                  spatial_avg_factor=int(rng.choice([1, 2, 3])), order=str(rng.choice(["F", "C"])),
+                  compute_normalizer=bool(rng.random() < 0.8), max_consecutive_failures=int(rng.choice([1, 1, 2])))
+        if rng.random() < 0.25 and frames >= 400:
+            wc = int(frames // 2 // taf * taf)
+            if wc >= 100:
+                kw["window_chunks"] = wc
+        out.append((case, T, d1, d2, b1, b2, frames, kw))
+    return out
+
+
+def passing_span_singular_values(res, passed, n_tile_cols, mov, mean_img, std_img, order):
+    """Singular values (float64) of the standardised movie projected on span(U[:, passing tile columns + background])."""
+    T = mov.shape[0]
+    u = res.u.tocsc()
+    keep = np.ones(u.shape[1], bool)
+    keep[:n_tile_cols] = passed
+    q, _ = np.linalg.qr(np.asarray(u[:, keep].todense(), dtype=np.float64))
+    y = ((mov.astype(np.float64) - mean_img[None]) / std_img[None]).reshape(T, -1, order=order).T
+    return np.linalg.svd(q.T @ y, compute_uv=False), int(keep.sum())
+
+
+def run_case(ctx, case, T, d1, d2, b1, b2, frames, kw, out=None):
+    """Returns a dict of the measured figures of one draw (and reports them through `out`)."""
+    say = out or (lambda s: None)
+    mov = tp._movie(T, d1, d2, seed=1000 + case)
+    # injected thresholds between the statistics of signal components and of noise (as in scripts/fuzz_parity.py)
+    pmd, diag, ref = tp._compare_full(ctx, mov, (b1, b2), frames, thresholds=(1.0, 1.7), **kw)
+    say(f"case {case}: T={T} fov={d1}x{d2} block={b1}x{b2} frames={frames} {kw}")
+    fig = {"pmd": pmd, "diag": diag, "ref": ref}
+    dr = diag["tile_ranks"].astype(int) - ref.diag["tile_ranks"].astype(int)
+    thr = diag["thresholds"]
+    knife = np.zeros(len(dr), dtype=bool)
+    for t, dl in enumerate(ref.diag["tile_diag"]):
+        for w in dl:
+            mrg = np.minimum(np.abs(w["spatial"] - thr[0]) / thr[0], np.abs(w["temporal"] - thr[1]) / thr[1])
+            knife[t] |= bool(np.any(mrg < 1e-2))
+    fig["rank_diff_tiles"] = np.nonzero(dr)[0]
+    fig["knife"] = knife
+    say(f"   tiles {len(dr)}, tile ranks differ in {int((dr != 0).sum())} tiles (knife-edge tiles: {int(knife.sum())}); components {len(pmd.s)} vs {len(ref.s)}")
+    n = min(len(pmd.s), len(ref.s))
+    k = max(1, n // 4)
+    rel = np.abs(pmd.s[:n] - ref.s[:n]) / ref.s[:n]
+    bad = np.nonzero(rel[:k] > 2e-3)[0]
+    fig["s_bad"] = bad
+    say(f"   top-quarter ({k}) singular values off by > 2e-3: indices {bad.tolist()}, values {np.round(ref.s[bad], 2).tolist()} "
+        f"(s1 = {ref.s[0]:.1f}), rel {np.round(rel[bad], 4).tolist()}")
+    if np.all(dr == 0):
+        hp, hg = PM.hip_cols(diag)
+        op, og = PM.oracle_cols(ref)
+        ntc = diag["n_tile_cols"]
+        both = hp & op
+        fig["decisions_equal"] = bool(np.array_equal(hp, op))
+        say(f"   tile columns {ntc}: passing on both sides {int(both.sum())}, kept failing {int((~hp).sum())} (HIP) / {int((~op).sum())} (oracle), "
+            f"decisions equal: {fig['decisions_equal']}")
+        mean64, std64 = ref.mean_img.astype(np.float64), ref.std_img.astype(np.float64)
+        sa, na = passing_span_singular_values(pmd, both, ntc, mov, mean64, std64, kw.get("order", "F"))
+        sb, _ = passing_span_singular_values(ref, both, ntc, mov, mean64, std64, kw.get("order", "F"))
+        relp = np.abs(sa - sb) / sb
+        kq = max(1, len(sa) // 4)
+        fig["span_s_rel_all"], fig["span_s_rel_top"] = float(relp.max()), float(relp[:kq].max())
+        say(f"   projected on the {na} passing columns (+ background): s rel diff max {relp.max():.2e} over all {len(sa)}, top-quarter {relp[:kq].max():.2e}")
+        if len(bad):
+            # where the offending values sit: next to the smallest singular values of the passing span = noise level
+            say(f"   offending values {np.round(ref.s[bad], 1).tolist()} vs the passing span's smallest value {sb[-1]:.1f} and median {np.median(sb):.1f}")
+        m = PM.measure(pmd, ref, (hp, hg), (op, og), ntc)
+        fig["measure"] = m
+        say(f"   U_data |diff| stable columns {m['u_data_err_stable']:.2e} ({m['n_stable_cols'][0]} of {m['n_stable_cols'][1]}), all columns "
+            f"{m['u_data_err_all']:.2e} (max |U_data| {m['u_data_max_abs']:.3f})")
+    else:
+        for t in np.nonzero(dr)[0][:6]:
+            say(f"   tile {t}: ranks {diag['tile_ranks'][t]} vs {ref.diag['tile_ranks'][t]}, knife-edge: {bool(knife[t])}")
+    # fit to the data on random probes (the quantity a user cares about)
+    rng_ = np.random.default_rng(0)
+    pi, pt = rng_.integers(0, d1 * d2, 600), rng_.integers(0, T, 600)
+    y = ((mov - ref.mean_img[None]) / ref.std_img[None]).reshape(T, -1, order=kw.get("order", "F"))[pt, pi]
+    rec = np.einsum("pk,k,kp->p", np.asarray(pmd.u.tocsr()[pi] @ pmd.r), pmd.s, pmd.v[:, pt])
+    rec0 = np.einsum("pk,k,kp->p", np.asarray(ref.u.tocsr()[pi] @ ref.r), ref.s, ref.v[:, pt])
+    fig["fit"] = (float(np.mean((rec - y) ** 2)), float(np.mean((rec0 - y) ** 2)))
+    say(f"   mean squared residual on 600 probes: {fig['fit'][0]:.4f} (HIP) / {fig['fit'][1]:.4f} (oracle)")
+    return fig
+
+
+_CASES = {c[0]: c for c in draw_cases(max(FUZZ_CASES) + 1)}
+
+
+@pytest.mark.parametrize("case", FUZZ_CASES)
+def test_fuzz_case(gpu_ctx, case):
+    lines = []
+    fig = run_case(gpu_ctx, *_CASES[case], out=lines.append)
+    print("\n".join(lines))
+    pmd, ref = fig["pmd"], fig["ref"]
+    assert np.all(np.isfinite(pmd.s)) and np.all(np.isfinite(pmd.v)) and np.all(np.isfinite(pmd.u.data)) and np.all(np.isfinite(pmd.r))
+    np.testing.assert_allclose(pmd.mean_img, ref.mean_img, rtol=1e-5)
+    np.testing.assert_allclose(pmd.var_img, ref.std_img, rtol=2e-4)
+    # tile ranks may differ only where a decision statistic sits within 1 % of its threshold
+    assert set(fig["rank_diff_tiles"].tolist()) <= set(np.nonzero(fig["knife"])[0].tolist()), fig["rank_diff_tiles"]
+    e1, e0 = fig["fit"]
+    assert abs(e1 - e0) < 0.05 * e0 + 1e-6, fig["fit"]
+    if len(fig["rank_diff_tiles"]) == 0:
+        assert pmd.r.shape == ref.r.shape and pmd.s.shape == ref.s.shape and pmd.v.shape == ref.v.shape
+        assert fig["measure"]["csr_equal"]
+        # the signal subspaces agree: singular values of the data on the span of the passing components
+        assert fig["span_s_rel_top"] < 1e-3 and fig["span_s_rel_all"] < 5e-3, (fig["span_s_rel_top"], fig["span_s_rel_all"])

@@ -293,3 +293,21 @@ def test_pmdarray_to_device_needs_a_gpu():
     with pytest.raises(PMDLibraryError):
         arr.to_device()
     assert arr[0].shape == (2, 3)
+
+
+def test_movie_upload_handles_one_frame_batches():
+    """lazy_data_loader.__getitem__ squeezes (dataset.py:114): a trailing batch of exactly one frame comes back 2-D
+    (T % frame_batch_size == 1).  The upload loop must not lose the frame axis."""
+    import types
+    import torch
+    from localmd_amd.dataset import ArrayDataset
+    from localmd_amd.decomposition import _Movie
+
+    rng = np.random.default_rng(0)
+    data = rng.random((11, 12, 13)).astype(np.float32)
+    fake_ctx = types.SimpleNamespace(device=torch.device("cpu"))
+    for fbs in (5, 10, 1, 11, 50):
+        mv = _Movie(fake_ctx, ArrayDataset(data), fbs)
+        np.testing.assert_array_equal(mv.dev.numpy(), data.reshape(11, -1))
+    mv = _Movie(fake_ctx, ArrayDataset(data), 10, rows=(3, 9))
+    np.testing.assert_array_equal(mv.dev.numpy(), data[:, 3:9, :].reshape(11, -1))
