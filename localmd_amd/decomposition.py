@@ -85,7 +85,7 @@ def _dbg(name, t):
 class _Movie:
     """The (T, D) float32 movie resident in HBM, plus the pixel-major standardised copies."""
 
-    def __init__(self, ctx, dataset_obj, frame_batch_size, rows=None):
+    def __init__(self, ctx, dataset_obj, frame_batch_size, rows=None, num_workers=0):
         """rows = (i_lo, i_hi): keep only these FOV rows (first spatial axis) - the pixel slab of one rank.
         self.D is the number of resident pixels; pixel c of the slab is FOV pixel c + i_lo * d2 (C order)."""
         torch = _torch()
@@ -102,15 +102,67 @@ class _Movie:
             self.dev = mv.reshape(self.T, self.D).contiguous()
         else:
             self.dev = torch.empty((self.T, self.D), dtype=torch.float32, device=ctx.device)
-            step = max(1, int(frame_batch_size))
-            for t0 in range(0, self.T, step):
-                keys = list(range(t0, min(self.T, t0 + step)))
-                # lazy_data_loader.__getitem__ ends with .squeeze() (dataset.py:114): a one-frame batch comes back 2-D
-                chunk = np.asarray(dataset_obj[keys], dtype=np.float32).reshape(len(keys), self.d1, self.d2)
-                chunk = chunk[:, i_lo:i_hi, :].reshape(len(keys), self.D)
-                self.dev[t0 : t0 + len(keys)].copy_(torch.from_numpy(np.ascontiguousarray(chunk)))
+            self._stream_in(dataset_obj, frame_batch_size, i_lo, i_hi, num_workers)
         # one extra block of zero rows: kernels that walk the rows in 1024-blocks may start at any owned offset
         self.rows_alloc = _round_up(self.D, 1024) + 1024
+
+    # Host -> HBM ingestion (reference: FrameDataloader + torch DataLoader workers, pmd_loader.py:71-108,
+    # :151-168, reading a lazy_data_loader such as TiffArray, dataset.py:131-181).  Frame batches are read / decoded by
+    # worker threads straight into page-locked staging buffers (a ring of STAGE_BUFFERS) and leave by asynchronous DMA
+    # on a copy stream, so decoding batch k + 1 overlaps the transfer of batch k; a buffer is reused once the event
+    # recorded behind its transfer has completed.
+    STAGE_BUFFERS = 3
+    STAGE_BYTES = 256 << 20
+
+    def _stream_in(self, dataset_obj, frame_batch_size, i_lo, i_hi, num_workers):
+        torch = _torch()
+        from concurrent.futures import ThreadPoolExecutor
+
+        on_gpu = self.ctx.device.type == "cuda"
+        frame_bytes = 4 * self.D
+        step = max(1, min(int(frame_batch_size), self.STAGE_BYTES // max(frame_bytes, 1), self.T))
+        n_threads = int(num_workers) if num_workers and num_workers > 0 else min(8, os.cpu_count() or 1)
+        is_array = isinstance(dataset_obj, np.ndarray)
+        full_rows = (i_lo == 0 and i_hi == self.d1)
+        stage = [torch.empty((step, self.D), dtype=torch.float32, pin_memory=on_gpu) for _ in range(self.STAGE_BUFFERS)]
+        stage_np = [b.numpy() for b in stage]
+        done = [None] * self.STAGE_BUFFERS
+        copy_stream = _side_stream(self.ctx.device) if on_gpu else None
+        if on_gpu:
+            copy_stream.wait_stream(torch.cuda.current_stream(self.ctx.device))   # self.dev may reuse a block still in use
+
+        def fill(buf, t0, t1):
+            """frames [t0, t1) -> rows [t0 - base, t1 - base) of staging buffer `buf` (runs on a worker thread)."""
+            base = fill.base
+            if is_array:
+                src = dataset_obj[t0:t1] if full_rows else dataset_obj[t0:t1, i_lo:i_hi, :]
+            else:
+                # lazy_data_loader.__getitem__ ends with .squeeze() (dataset.py:114): a one-frame batch comes back 2-D
+                src = np.asarray(dataset_obj[list(range(t0, t1))]).reshape(t1 - t0, self.d1, self.d2)
+                if not full_rows:
+                    src = src[:, i_lo:i_hi, :]
+            np.copyto(stage_np[buf][t0 - base:t1 - base].reshape(t1 - t0, i_hi - i_lo, self.d2), src, casting="unsafe")
+
+        with ThreadPoolExecutor(max_workers=n_threads) as pool:
+            for k, base in enumerate(range(0, self.T, step)):
+                buf = k % self.STAGE_BUFFERS
+                n = min(step, self.T - base)
+                if done[buf] is not None:
+                    done[buf].synchronize()          # the transfer that last read this buffer has finished
+                fill.base = base
+                parts = max(1, min(n_threads, n))
+                edges = [base + (n * j) // parts for j in range(parts + 1)]
+                for f in [pool.submit(fill, buf, edges[j], edges[j + 1]) for j in range(parts)]:
+                    f.result()
+                if on_gpu:
+                    with torch.cuda.stream(copy_stream):
+                        self.dev[base:base + n].copy_(stage[buf][:n], non_blocking=True)
+                        done[buf] = torch.cuda.Event()
+                        done[buf].record(copy_stream)
+                else:
+                    self.dev[base:base + n].copy_(stage[buf][:n])
+        if on_gpu:
+            torch.cuda.current_stream(self.ctx.device).wait_stream(copy_stream)
 
     def standardized(self, frames, mean, std):
         """Pixel-major (rows_alloc x ld) standardised frames; frames=None means all, in order."""
@@ -393,7 +445,7 @@ def localmd_decomposition(
 
         # ---- PMDLoader.__init__ (pmd_loader.py:112-173): movie to HBM, statistics, background basis
         t0 = time.perf_counter()
-        movie = _Movie(ctx, dataset_obj, frame_batch_size, rows=(i_lo, i_hi) if dist.enabled else None)
+        movie = _Movie(ctx, dataset_obj, frame_batch_size, rows=(i_lo, i_hi) if dist.enabled else None, num_workers=num_workers)
         Dl = movie.D   # resident pixels (= D unless distributed)
         lap("upload", t0)
         display("Computing Video Statistics")
@@ -700,6 +752,7 @@ def localmd_decomposition(
         _dbg("v_cropped", vc)
         P_dev = Et_dev = None
         chol_ok = False
+        null_tail = False
         shard = False               # rows of right / GM / Z / R split over the ranks (Cholesky route only)
         row_lo, row_hi = 0, Rc
         Z = W1 = None
@@ -829,9 +882,19 @@ def localmd_decomposition(
                     dist.all_reduce(W1)
                 else:
                     Z = W1 = None   # eigenvector route below: full Z, M^T Z inside pmd_projected_svd_factored
+                null_tail = False
                 if chol_ok:
                     rp = m_eff
                     m_used = m_eff
+                    if abs_last:
+                        # The last row of Et is the kept numerically null direction (scale 1 / sqrt(|last pivot|), as the
+                        # reference's 1 / sqrt(|lambda|), decomposition.py:984-996).  Its coupling to the other directions is
+                        # rounding noise, so it is carried as one extra component next to the SVD of the leading
+                        # m - 1 directions (whose Et block is exactly the Cholesky inverse of the deflated matrix)
+                        # instead of through it, where its huge coefficients would amplify rounding errors into every
+                        # other component.
+                        null_tail = True
+                        rp = m_used = m_eff - 1
                 elif orthogonalizer == "cholesky":
                     raise PMDLibraryError("orthogonalizer='cholesky': U^T U restricted to the right matrix is not positive definite")
             if not chol_ok:
@@ -852,7 +915,7 @@ def localmd_decomposition(
             _dbg("G", G)
             P_dev, rp = _orthogonalize(ctx, G, Rc, None, m_cols, m_cols)
             del G
-        display("After performing rank reduction, the updated rank is {}".format(rp))
+        display("After performing rank reduction, the updated rank is {}".format(rp + (1 if null_tail else 0)))
         lap("orthogonalize", t0)
 
         # ---- V = P^T U^T X over the whole movie (pmd_loader.py:316-346); already enqueued on the Cholesky route
@@ -876,15 +939,16 @@ def localmd_decomposition(
         hosts = None
         if use_right and rp <= T:
             nk = rp
+            nko = nk + (1 if null_tail else 0)   # components in the outputs
             # device copy of R only where rows are exchanged between ranks; rank 0's own rows go straight to the host
             # Zero copy only for the large case it was measured on: for small outputs rocBLAS may pick split-K kernels
             # that read-modify-write C, which is ruinous across PCIe (58 ms instead of 1 ms at 5015 x 1999).
             # (not with PMD_GEMM_SPLIT: its passes accumulate into C, which must then live in HBM)
             split_gemm = os.environ.get("PMD_GEMM_SPLIT", "0") in ("3", "6")
             zero_copy = (not shard or dist.rank == 0) and m_used >= 8192 and Rc * nk * 4 >= 2 ** 30 and not split_gemm
-            R_out = torch.empty((Rc, nk), dtype=torch.float32, device=ctx.device) if (shard or not zero_copy) else None
-            s_out = torch.empty((nk,), dtype=torch.float32, device=ctx.device)
-            Vt_out = torch.empty((nk, T), dtype=torch.float32, device=ctx.device)
+            R_out = torch.empty((Rc, nko), dtype=torch.float32, device=ctx.device) if (shard or not zero_copy) else None
+            s_out = torch.empty((nko,), dtype=torch.float32, device=ctx.device)
+            Vt_out = torch.empty((nko, T), dtype=torch.float32, device=ctx.device)
             X1 = torch.empty((m_used, rp), dtype=torch.float32, device=ctx.device)
             # W1 = M^T Z was formed next to the Cholesky step (summed over the ranks when the rows are sharded);
             # None on the eigenvector route (formed inside the call)
@@ -892,15 +956,26 @@ def localmd_decomposition(
             ctx.call("pmd_projected_svd_factored", ptr(right), Rc, m_used, m_cols, ptr(Et_dev), rp, m_cols, ptr(Z), T, T,
                      None, nk, ptr(s_out), ptr(Vt_out), T, ptr(Vp), T, ptr(X1), ptr(W1), 1 if chol_ok else 0, ptr(ws),
                      ws.numel())
+            p_null = None
+            if null_tail:
+                # the kept null direction: P column = right Et[m-1, :]^T, V row = Et[m-1, :] (right^T Z), its own
+                # singular triple (s = |V row|, Vt = V row / s, R column = P column) appended as the last component
+                m_full = m_used + 1
+                et_row = Et_dev[m_full - 1, :m_full]
+                v_null = Vt_out[nk:nk + 1]
+                ctx.call("pmd_gemm", 0, 0, 1, T, m_full, 1.0, ptr(et_row), m_full, ptr(W1), T, 0.0, ptr(v_null), T)
+                s_null = v_null.norm()
+                s_out[nk:nk + 1] = s_null
+                v_null.div_(torch.where(s_null == 0, torch.ones_like(s_null), s_null))
             # R = right X1 in row blocks; s, Vt and every finished block go to the host on a side stream
             # while the next block is computed (2.6 GB of results, ~45 ms of PCIe time otherwise serial)
             main = torch.cuda.current_stream(ctx.device)
             side = _side_stream(ctx.device)
             root = dist.rank == 0
             if root:
-                r_host = torch.empty((Rc + extra_row, nk), dtype=torch.float32, pin_memory=True)
-                s_host = torch.empty((nk,), dtype=torch.float32, pin_memory=True)
-                vt_host = torch.empty((nk, T), dtype=torch.float32, pin_memory=True)
+                r_host = torch.empty((Rc + extra_row, nko), dtype=torch.float32, pin_memory=True)
+                s_host = torch.empty((nko,), dtype=torch.float32, pin_memory=True)
+                vt_host = torch.empty((nko, T), dtype=torch.float32, pin_memory=True)
                 if extra_row:
                     r_host[Rc:].zero_()
                 ev = torch.cuda.Event()
@@ -923,8 +998,18 @@ def localmd_decomposition(
             r_lo, r_hi = (row_lo, row_hi) if shard else (0, Rc)
             if r_hi > r_lo:
                 dst = r_host[r_lo:] if (root and zero_copy) else R_out[r_lo:]
+                if null_tail:
+                    # last column first (a small product and, on the zero-copy path, a blocking copy: before the large
+                    # asynchronous GEMM is enqueued, which writes the other columns of the same rows)
+                    p_null = torch.empty((r_hi - r_lo, 1), dtype=torch.float32, device=ctx.device)
+                    ctx.call("pmd_gemm", 0, 0, r_hi - r_lo, 1, m_full, 1.0, ptr(right[r_lo:]), m_cols, ptr(et_row), 1, 0.0,
+                             ptr(p_null), 1)
+                    if root and zero_copy:
+                        r_host[r_lo:r_hi, nk:nko].copy_(p_null)
+                    else:
+                        R_out[r_lo:r_hi, nk:nko] = p_null
                 ctx.call("pmd_gemm", 0, 0, r_hi - r_lo, nk, m_used, 1.0, ptr(right[r_lo:]), m_cols, ptr(X1), rp, 0.0,
-                         ptr(dst), nk)
+                         ptr(dst), nko)
                 if root and not zero_copy:
                     download(r_lo, r_hi)
             if shard:
@@ -965,6 +1050,10 @@ def localmd_decomposition(
             if extra_row:
                 r_mat = np.concatenate([r_mat, np.zeros((1, r_mat.shape[1]), dtype=r_mat.dtype)], axis=0)
         if not root_only:
+            if null_tail and len(s) > 1 and s[-1] > s[-2]:
+                # the appended component is normally the smallest; keep `s` descending in any case (as svd returns it)
+                order_s = np.argsort(-s, kind="stable")
+                r_mat, s, vt = r_mat[:, order_s], s[order_s], vt[order_s]
             good_components = s != 0
             if not np.all(good_components):
                 r_mat = r_mat[:, good_components]
@@ -992,9 +1081,9 @@ def localmd_decomposition(
             "sim_stats": sim_stats, "tile_ranks": ranks.astype(np.int32), "tile_stats": stats_dev.cpu().numpy(),
             "tile_good": good_dev.cpu().numpy(), "tile_keep": keep_dev.cpu().numpy(), "tile_lambda": lam_dev.cpu().numpy(),
             "tile_ut": ut_dev.cpu().numpy(), "origins": origins, "pix": pix_c, "block_weights": block_weights,
-            "max_components": r, "rank_before": R, "rank_after": rp, "timings": timings,
+            "max_components": r, "rank_before": R, "rank_after": rp + (1 if null_tail else 0), "timings": timings,
             "orthogonalizer": ("cholesky" if (use_right and chol_ok) else "eigh"),
-            "crop": crop, "dpad": dpad, "v_proj": Vp.cpu().numpy(), "col_sigma": col_sigma, "n_tile_cols": Rt,
+            "crop": crop, "dpad": dpad, "v_proj": Vp.cpu().numpy(), "eig_order": min(rp, T), "col_sigma": col_sigma, "n_tile_cols": Rt,
         }
         return final_movie, diag
     finally:

@@ -39,6 +39,7 @@ def _assert_common(res, u_tol, s_sig, vt_sig, ur_sig, r_sig, probe_tol, orth_tol
     assert m["r_err_stable_signal"] < r_sig * m["r_max_abs"], (m["r_err_stable_signal"], m["r_max_abs"])
     assert res["probes"]["HIP vs oracle fp32"] < probe_tol
     assert m["orth_ur"][0] < orth_tol and m["orth_vt"][0] < orth_tol, (m["orth_ur"], m["orth_vt"])
+    assert m["orth_ur_weighted"][0] < 1e-4 and m["orth_vt_weighted"][0] < 1e-5, (m["orth_ur_weighted"], m["orth_vt_weighted"])
     return m
 
 
