@@ -134,7 +134,11 @@ int pmd_launch_small_qr(pmd_ctx* ctx, const float* Yt, long y_tile_stride, int y
 //   mode 1: column c scaled by 1/sqrt(lambda_c); columns with lambda_c <= tol*lambda_max zeroed
 // lam_out[tile][c] = eigenvalue c (descending); entries >= n are zero.
 #define EIG_LD 65
-#define EIG_THREADS 1024  // one 2x2 block of the rotation step per thread at n = 60: the step is latency bound
+// Threads per problem.  A problem holds 66.5 KB of LDS (A and V in fp64), so two share a CU whatever the workgroup
+// size; one rotation step is ~18 000 fp64 FMAs (A <- J^T A J and V <- V J at n = 60) between two barriers.  With 1024
+// threads (one 2 x 2 block each) the step is bound by the barriers of 16 waves and the LDS round trips; with 256
+// threads a wave keeps four blocks in flight and the barrier joins four waves (measured: PMD_EIG_THREADS=256|512|1024).
+template <int EIG_THREADS>
 __global__ __launch_bounds__(EIG_THREADS) void small_eig_kernel(const double* __restrict__ G, long g_tile_stride, int slices,
                                                         int n, int mode, double tol, double* __restrict__ Nout,
                                                         double* __restrict__ lam_out) {
@@ -261,9 +265,22 @@ int pmd_launch_small_eig(pmd_ctx* ctx, const double* G, int slices, int n, int m
   if (n_tiles <= 0) return PMD_OK;
   if (n > 64 || n < 1) return pmd_fail(ctx, PMD_ERR_UNSUPPORTED, "small_eig", "n must be in [1, 64]");
   const size_t bytes = (size_t)2 * 64 * EIG_LD * sizeof(double) + 64 * sizeof(double) + (64 + 2 + 64) * sizeof(int) + 64;
-  PMD_HIP(ctx, hipFuncSetAttribute((const void*)small_eig_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-  hipLaunchKernelGGL(small_eig_kernel, dim3(n_tiles), dim3(EIG_THREADS), bytes, ctx->stream, G, (long)slices * 4096, slices, n,
-                     mode, tol, Nout, lam_out);
+  static int threads = 0;
+  if (!threads) {
+    const char* e = getenv("PMD_EIG_THREADS");
+    threads = e ? atoi(e) : 256;
+    if (threads != 256 && threads != 512 && threads != 1024) threads = 256;
+  }
+#define PMD_EIG_LAUNCH(TH)                                                                                                      \
+  do {                                                                                                                          \
+    PMD_HIP(ctx, hipFuncSetAttribute((const void*)small_eig_kernel<TH>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes)); \
+    hipLaunchKernelGGL(small_eig_kernel<TH>, dim3(n_tiles), dim3(TH), bytes, ctx->stream, G, (long)slices * 4096, slices, n,    \
+                       mode, tol, Nout, lam_out);                                                                               \
+  } while (0)
+  if (threads == 1024) PMD_EIG_LAUNCH(1024);
+  else if (threads == 512) PMD_EIG_LAUNCH(512);
+  else PMD_EIG_LAUNCH(256);
+#undef PMD_EIG_LAUNCH
   PMD_LAUNCH_CHECK(ctx, "small_eig_kernel");
   return PMD_OK;
 }

@@ -569,6 +569,14 @@ def localmd_decomposition(
         n_win = len(win_starts)
         if n_win > 1 and win_len % temporal_avg_factor != 0:
             raise ValueError("window_chunks must be a multiple of temporal_avg_factor")
+        if crop < Tf:
+            # The tile fits use the first `crop` fitted frames only (decomposition.py:773-774, :796), and the tile
+            # kernels walk the time axis in 32-frame chunks relying on zeros behind the last frame they are given:
+            # frames crop .. Tf - 1 of the filtered copy must not leak into the contractions.  (Found by the seeded
+            # fuzz of round 2: every draw with frames % temporal_avg_factor != 0 was off by ~1e-3 in its tile bases.)
+            if xf.data_ptr() == xs_init.data_ptr():
+                xf = xs_init.clone()    # xs_init may be the standardised movie the V projection still needs
+            xf[:, crop:Tf].zero_()
         pix_c, origins = grid.tile_pixel_lists((d1, d2), block_sizes, dim_1_iters, dim_2_iters)
         n_tiles = pix_c.shape[0]
         pool_q, pool_idx, pool_w, pooled_shape = grid.pooling_maps(block_sizes, int(spatial_avg_factor))
@@ -733,7 +741,7 @@ def localmd_decomposition(
         if n_loc > 0:
             ctx.call("pmd_compact_rows", ptr(v_dev[t_lo:]), ldv, ptr(col_off_dev[t_lo:]), ptr(ranks_dev[t_lo:]), crop, ptr(vc),
                      m_cols, n_loc)
-        dist.gather_runs(vc, [(int(offsets[lo]), int(offsets[hi])) for lo, hi in runs])
+        row_bounds = [(int(offsets[lo]), int(offsets[hi])) for lo, hi in runs]
         if K > 0:
             vc[Rt:Rt + K, :] = pj_dev[:, :crop]
         right = vc
@@ -749,6 +757,23 @@ def localmd_decomposition(
             ctx.call("pmd_gemm", 0, 0, Rc, n_rand, crop, 1.0, ptr(vc), m_cols, ptr(rand), n_rand, 0.0, ptr(right), n_rand)
             m_cols = n_rand
         use_right = R > m_cols  # decomposition.py:976 (R counts the placeholder column too)
+        # Rows of `right` that live on other ranks.  Row-sharded Cholesky route: a rank applies the block-sparse Gram
+        # matrix to its own tiles only and needs, besides its own rows, the rows of the foreign tiles that overlap
+        # them (a halo of one or two tile rows on either side: tens of MB instead of the whole 2.2 GB matrix at
+        # config 3).  Every other route is replicated and collects all rows.
+        will_shard = dist.enabled and use_right and orthogonalizer in ("auto", "cholesky")
+        if will_shard:
+            tile_owner = np.searchsorted(np.asarray([hi for _, hi in runs]), np.arange(n_tiles), side="right")
+            needs = [[] for _ in range(dist.world)]
+            pa, pb = pairs[:, 0].astype(np.int64), pairs[:, 1].astype(np.int64)
+            for a_t, b_t in ((pa, pb), (pb, pa)):
+                cross = tile_owner[a_t] != tile_owner[b_t]
+                for rr in range(dist.world):
+                    for t in np.unique(b_t[cross & (tile_owner[a_t] == rr)]):
+                        needs[rr].append((int(offsets[t]), int(offsets[t + 1])))
+            dist.exchange_rows(right, row_bounds, [sorted(set(x for x in nd if x[1] > x[0])) for nd in needs])
+        elif dist.enabled:
+            dist.gather_runs(right, row_bounds)
         _dbg("v_cropped", vc)
         P_dev = Et_dev = None
         chol_ok = False
@@ -898,6 +923,8 @@ def localmd_decomposition(
                 elif orthogonalizer == "cholesky":
                     raise PMDLibraryError("orthogonalizer='cholesky': U^T U restricted to the right matrix is not positive definite")
             if not chol_ok:
+                if shard:
+                    dist.gather_runs(right, row_bounds)   # only the halo rows were exchanged so far
                 shard = False  # eigenvector route: replicated on every rank
                 row_lo, row_hi = 0, Rc
                 gram_apply(m_cols)
@@ -964,6 +991,12 @@ def localmd_decomposition(
                 et_row = Et_dev[m_full - 1, :m_full]
                 v_null = Vt_out[nk:nk + 1]
                 ctx.call("pmd_gemm", 0, 0, 1, T, m_full, 1.0, ptr(et_row), m_full, ptr(W1), T, 0.0, ptr(v_null), T)
+                # the joint SVD of the reference would deflate this row against the other right vectors: do the same
+                # (two passes of classical Gram-Schmidt against the orthonormal rows of Vt), so that Vt stays orthonormal
+                coef = torch.empty((nk,), dtype=torch.float32, device=ctx.device)
+                for _ in range(2):
+                    ctx.call("pmd_gemm", 0, 0, nk, 1, T, 1.0, ptr(Vt_out), T, ptr(v_null), 1, 0.0, ptr(coef), 1)
+                    ctx.call("pmd_gemm", 0, 0, 1, T, nk, -1.0, ptr(coef), nk, ptr(Vt_out), T, 1.0, ptr(v_null), T)
                 s_null = v_null.norm()
                 s_out[nk:nk + 1] = s_null
                 v_null.div_(torch.where(s_null == 0, torch.ones_like(s_null), s_null))

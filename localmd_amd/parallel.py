@@ -38,15 +38,69 @@ class Dist:
 
     def gather_runs(self, tensor, bounds):
         """Every rank owns rows [bounds[r][0], bounds[r][1]) of ``tensor`` (dim 0) and has filled them;
-        after the call every rank holds all rows.  One broadcast per owner (runs may differ in length)."""
+        after the call every rank holds all rows.  ONE all-gather (RCCL: every link carries 1 / world of the data once);
+        runs may differ in length, so every rank contributes a block padded to the longest run."""
         if not self.enabled:
             return
         import torch.distributed as dist
 
-        for r, (lo, hi) in enumerate(bounds):
-            if hi > lo:
-                dist.broadcast(tensor[lo:hi], src=dist.get_global_rank(self.group, r) if self.group is not None else r,
-                               group=self.group)
+        lens = [max(0, hi - lo) for lo, hi in bounds]
+        longest = max(lens)
+        if longest == 0:
+            return
+        lo, hi = bounds[self.rank]
+        send = tensor.new_empty((longest,) + tuple(tensor.shape[1:]))
+        send[:hi - lo] = tensor[lo:hi]
+        recv = tensor.new_empty((self.world * longest,) + tuple(tensor.shape[1:]))
+        dist.all_gather(list(recv.split(longest, dim=0)), send, group=self.group)
+        for r, (rlo, rhi) in enumerate(bounds):
+            if r != self.rank and rhi > rlo:
+                tensor[rlo:rhi] = recv[r * longest:r * longest + (rhi - rlo)]
+
+    def exchange_rows(self, tensor, bounds, needs):
+        """Halo exchange.  Rank r owns rows [bounds[r][0], bounds[r][1]) of ``tensor``; needs[r] is a list of foreign row
+        ranges (lo, hi) rank r must also hold (every rank passes the same ``bounds`` and ``needs``).  Afterwards every
+        rank holds its needs; nothing else moves.  RCCL: one batch of point-to-point sends / receives between the ranks
+        involved; other backends (gloo cannot send device tensors point to point): one broadcast per requested range."""
+        if not self.enabled:
+            return
+        import torch.distributed as dist
+
+        def owner(row):
+            for r, (lo, hi) in enumerate(bounds):
+                if lo <= row < hi:
+                    return r
+            raise ValueError("row {} has no owner".format(row))
+
+        def grank(r):
+            return dist.get_global_rank(self.group, r) if self.group is not None else r
+
+        # split every requested range at ownership boundaries: (destination, source, lo, hi)
+        moves = []
+        for dst, ranges in enumerate(needs):
+            for lo, hi in ranges:
+                while lo < hi:
+                    src = owner(lo)
+                    top = min(hi, bounds[src][1])
+                    if src != dst:
+                        moves.append((dst, src, lo, top))
+                    lo = top
+        if dist.get_backend(self.group) == "nccl":
+            ops = []
+            for dst, src, lo, hi in moves:
+                if src == self.rank:
+                    ops.append(dist.P2POp(dist.isend, tensor[lo:hi], grank(dst), self.group))
+                elif dst == self.rank:
+                    ops.append(dist.P2POp(dist.irecv, tensor[lo:hi], grank(src), self.group))
+            for req in (dist.batch_isend_irecv(ops) if ops else []):
+                req.wait()
+        else:
+            # a broadcast is collective: every rank takes part; a rank that did not ask for a range receives it into
+            # a scratch copy (its own rows of that range, if any, stay untouched)
+            for src, lo, hi in sorted(set((src, lo, hi) for _, src, lo, hi in moves)):
+                wanted = self.rank == src or any(d == self.rank and (s_, l_, h_) == (src, lo, hi) for d, s_, l_, h_ in moves)
+                buf = tensor[lo:hi] if wanted else tensor[lo:hi].clone()
+                dist.broadcast(buf, src=grank(src), group=self.group)
 
     def broadcast_object(self, obj):
         """Rank 0's value of a small Python object on every rank (seeds, the random frame sample)."""

@@ -44,7 +44,9 @@ for name, mov, blk, kw in cases:
     if a is not None:
         ok = ok and np.array_equal(a.u.indices, b.u.indices) and np.allclose(a.u.data, b.u.data, atol=5e-4)
         ok = ok and np.array_equal(a.mean_img, b.mean_img) and np.array_equal(a.var_img, b.var_img)
-        ok = ok and a.s.shape == b.s.shape and np.allclose(a.s, b.s, rtol=2e-4)
+        # strong singular values to fp32 summation order; the weak ones of the ill-conditioned routes (eigenvector
+        # orthogonaliser, rank_prune) carry eps (s_1 / s_c)^2 of relative error on either side
+        ok = ok and a.s.shape == b.s.shape and np.all(np.abs(a.s - b.s) <= np.maximum(2e-4, 2e-6 * (b.s[0] / np.maximum(b.s, 1e-30)) ** 2) * b.s)
         rng = np.random.default_rng(0)
         pi = rng.integers(0, mov.shape[1] * mov.shape[2], 300)
         pt = rng.integers(0, T, 300)

@@ -125,3 +125,45 @@ def test_single_process_dist_is_a_noop():
     d.barrier()
     with pytest.raises(RuntimeError):
         Dist(True)
+
+
+def _worker_halo(rank, world, port, out_dir):
+    """exchange_rows: every rank ends up with its own rows plus the requested halo rows of its neighbours, and with
+    nothing else (rows nobody sent stay at their fill value)."""
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        d = Dist(True)
+        bounds = [(0, 7), (7, 12), (12, 20)]
+        needs = [[(7, 9)], [(5, 7), (12, 13)], [(10, 12), (3, 4)]]
+        x = torch.full((20, 3), -1.0)
+        lo, hi = bounds[rank]
+        x[lo:hi] = torch.arange(lo, hi, dtype=torch.float32)[:, None] + 100.0 * rank
+        d.exchange_rows(x, bounds, needs)
+        np.save(os.path.join(out_dir, f"halo{rank}.npy"), x.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_exchange_rows_world3_gloo(tmp_path):
+    import torch.multiprocessing as mp
+
+    world = 3
+    mp.spawn(_worker_halo, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    bounds = [(0, 7), (7, 12), (12, 20)]
+    needs = [[(7, 9)], [(5, 7), (12, 13)], [(10, 12), (3, 4)]]
+    full = np.empty((20, 3), dtype=np.float32)
+    for r, (lo, hi) in enumerate(bounds):
+        full[lo:hi] = np.arange(lo, hi, dtype=np.float32)[:, None] + 100.0 * r
+    for r in range(world):
+        got = np.load(tmp_path / f"halo{r}.npy")
+        have = np.zeros(20, dtype=bool)
+        have[bounds[r][0]:bounds[r][1]] = True
+        for lo, hi in needs[r]:
+            have[lo:hi] = True
+        np.testing.assert_array_equal(got[have], full[have])
+        assert np.all(got[~have] == -1.0)
