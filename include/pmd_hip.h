@@ -221,6 +221,23 @@ int pmd_gemm(pmd_ctx* ctx, int transA, int transB, int m, int n, int k, float al
  * or R diag(s).  pmd_transpose_affine: dst[c][r] = src[r][c] * scale[r] + shift[r] (scale / shift may be NULL). */
 int pmd_csr_rows_spmm(pmd_ctx* ctx, const int64_t* indptr, const int* indices, const float* data, const int* rows, long n_sel,
                       const float* B, long ldb, int ncols, float* out, long ldo);
+/* SURVEY 8(f)4 - the local correlation images of /root/reference/localmd/diagnostic_plots.py (their O(D) Python loops of
+ * jitted per-pair calls, :131-156, :195-221, :247-268, :293-302) from first and second moments of the pixel traces.
+ * Movies are frames first (T, d1, d2) float32 on the device; ref[D] = one frame of the movie (the traces are shifted by it,
+ * covariances do not change).  pmd_neighbour_moments: moments[10][D] (+)= {sum x, sum x^2, sum x_p x_q for the 8 neighbours
+ * q in row-major (di, dj) order} of x = A - B (B may be NULL); call it once per resident chunk of frames with accumulate = 1
+ * after the first.  pmd_neighbour_image: kind 0 = Pearson correlation (make_correlation_image), kind 1 = cov(ddof 1) of the
+ * numerator movie over sqrt(var var) (ddof 0) of the normalising movie `den` = its moments[0..1] (make_pmd_correlation_image,
+ * make_residual_correlation_image); mode 0 = max over the existing neighbours starting from 0, mode 1 = their mean.
+ * pmd_lag_moments / pmd_lag_image: make_autocorrelation_image; moments[5][D] (+)= sums over the pairs (t, t - lag), t in
+ * [lag, T) of the resident frames (a chunk therefore starts `lag` frames before its first new frame); n = T_total - lag. */
+size_t pmd_diag_workspace_bytes(long T, long D);
+int pmd_neighbour_moments(pmd_ctx* ctx, const float* A, const float* B, const float* ref, long T, int d1, int d2, int accumulate,
+                          double* moments, void* ws, size_t ws_bytes);
+int pmd_lag_moments(pmd_ctx* ctx, const float* A, const float* ref, long T, long D, int lag, int accumulate, double* moments,
+                    void* ws, size_t ws_bytes);
+int pmd_neighbour_image(pmd_ctx* ctx, const double* num, const double* den, long T, int d1, int d2, int kind, int mode, double* out);
+int pmd_lag_image(pmd_ctx* ctx, const double* moments, long D, long n, double* out);
 int pmd_transpose_affine(pmd_ctx* ctx, const float* src, long lds_, long rows, int cols, const float* scale,
                          const float* shift, float* dst, long ldd);
 

@@ -44,6 +44,11 @@ SIGNATURES = {
     "pmd_tiles_decompose_staged": (c_i, [c_p, c_p, c_l, c_l, c_i, c_p, c_i, c_i, c_i, c_p, c_i, c_i, c_p, c_p, c_i, c_i, c_f,
                                          c_f, c_i, c_u64, c_u32, c_u32, c_p, c_p, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_sz, c_i]),
     "pmd_csr_rows_spmm": (c_i, [c_p, c_p, c_p, c_p, c_p, c_l, c_p, c_l, c_i, c_p, c_l]),
+    "pmd_diag_workspace_bytes": (c_sz, [c_l, c_l]),
+    "pmd_neighbour_moments": (c_i, [c_p, c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_p, c_p, c_sz]),
+    "pmd_lag_moments": (c_i, [c_p, c_p, c_p, c_l, c_l, c_i, c_i, c_p, c_p, c_sz]),
+    "pmd_neighbour_image": (c_i, [c_p, c_p, c_p, c_l, c_i, c_i, c_i, c_i, c_p]),
+    "pmd_lag_image": (c_i, [c_p, c_p, c_l, c_l, c_p]),
     "pmd_transpose_affine": (c_i, [c_p, c_p, c_l, c_l, c_i, c_p, c_p, c_p, c_l]),
     "pmd_tiles_hook_offsets": (c_i, [c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_l, c_l, c_p, c_p]),
     "pmd_tiles_residual_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i, c_i, c_l]),

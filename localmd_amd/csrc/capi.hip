@@ -279,6 +279,29 @@ int pmd_csr_rows_spmm(pmd_ctx* ctx, const int64_t* indptr, const int* indices, c
   if (!indptr || !indices || !data || !B || !out) return pmd_fail(ctx, PMD_ERR_ARG, "pmd_csr_rows_spmm", "null pointer");
   return pmd_csr_rows_spmm_impl(ctx, (const long*)indptr, indices, data, rows, n_sel, B, ldb, ncols, out, ldo);
 }
+size_t pmd_diag_workspace_bytes(long T, long D) { return pmd_diag_workspace_bytes_impl(T, D); }
+int pmd_neighbour_moments(pmd_ctx* ctx, const float* A, const float* B, const float* ref, long T, int d1, int d2, int accumulate,
+                          double* moments, void* ws, size_t ws_bytes) {
+  CTX_CHECK(ctx);
+  if (!A || !ref || !moments || !ws || d1 < 1 || d2 < 1) return pmd_fail(ctx, PMD_ERR_ARG, "pmd_neighbour_moments", "bad argument");
+  return pmd_neighbour_moments_impl(ctx, A, B, ref, T, d1, d2, accumulate, moments, ws, ws_bytes);
+}
+int pmd_lag_moments(pmd_ctx* ctx, const float* A, const float* ref, long T, long D, int lag, int accumulate, double* moments,
+                    void* ws, size_t ws_bytes) {
+  CTX_CHECK(ctx);
+  if (!A || !ref || !moments || !ws || D < 1) return pmd_fail(ctx, PMD_ERR_ARG, "pmd_lag_moments", "bad argument");
+  return pmd_lag_moments_impl(ctx, A, ref, T, D, lag, accumulate, moments, ws, ws_bytes);
+}
+int pmd_neighbour_image(pmd_ctx* ctx, const double* num, const double* den, long T, int d1, int d2, int kind, int mode, double* out) {
+  CTX_CHECK(ctx);
+  if (!num || !out || T < 2 || (kind != 0 && kind != 1) || (mode != 0 && mode != 1)) return pmd_fail(ctx, PMD_ERR_ARG, "pmd_neighbour_image", "bad argument");
+  return pmd_neighbour_image_impl(ctx, num, den, T, d1, d2, kind, mode, out);
+}
+int pmd_lag_image(pmd_ctx* ctx, const double* moments, long D, long n, double* out) {
+  CTX_CHECK(ctx);
+  if (!moments || !out || n < 1) return pmd_fail(ctx, PMD_ERR_ARG, "pmd_lag_image", "bad argument");
+  return pmd_lag_image_impl(ctx, moments, D, n, out);
+}
 int pmd_transpose_affine(pmd_ctx* ctx, const float* src, long lds_, long rows, int cols, const float* scale,
                          const float* shift, float* dst, long ldd) {
   CTX_CHECK(ctx);

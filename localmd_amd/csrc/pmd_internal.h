@@ -57,6 +57,14 @@ int pmd_launch_decide(pmd_ctx* ctx, const float* stats, int r, float thr_s, floa
 // expand.hip
 int pmd_csr_rows_spmm_impl(pmd_ctx* ctx, const long* indptr, const int* indices, const float* data, const int* rows,
                            long n_sel, const float* B, long ldb, int ncols, float* out, long ldo);
+size_t pmd_diag_workspace_bytes_impl(long T, long D);
+int pmd_neighbour_moments_impl(pmd_ctx* ctx, const float* A, const float* B, const float* ref, long T, int d1, int d2,
+                               int accumulate, double* moments, void* ws, size_t ws_bytes);
+int pmd_lag_moments_impl(pmd_ctx* ctx, const float* A, const float* ref, long T, long D, int lag, int accumulate, double* moments,
+                         void* ws, size_t ws_bytes);
+int pmd_neighbour_image_impl(pmd_ctx* ctx, const double* num, const double* den, long T, int d1, int d2, int kind, int mode,
+                             double* out);
+int pmd_lag_image_impl(pmd_ctx* ctx, const double* moments, long D, long n, double* out);
 int pmd_transpose_affine_impl(pmd_ctx* ctx, const float* src, long lds_, long rows, int cols, const float* scale,
                               const float* shift, float* dst, long ldd);
 

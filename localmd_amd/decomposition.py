@@ -841,6 +841,17 @@ def localmd_decomposition(
                     ctx.call("pmd_gram_apply", ptr(gblk), ptr(gbg), ptr(gstrip), Rc, ptr(nbr_ptr_dev[a0:]), ptr(nbr_dev),
                              ptr(col_off_dev[a0:]), ptr(ranks_dev[a0:]), an, Rt, max(K, 0),
                              int(ranks.max()) if n_tiles else 0, ptr(right), ld_right, ncols, ptr(GM), m_cols)
+                if shard and K > 0:
+                    # The background rows of G M are sums over ALL rows of `right`; a rank holds its own rows and a halo
+                    # only.  Every rank contributes the product over the rows it owns (the last one also the background
+                    # columns), the K x ncols partials are all-reduced, their owner (the last rank) keeps the result.
+                    part = torch.zeros((K, ncols), dtype=torch.float32, device=ctx.device)
+                    lo_, hi_ = row_bounds[dist.rank][0], (Rc if dist.rank == dist.world - 1 else row_bounds[dist.rank][1])
+                    if hi_ > lo_:
+                        ctx.call("pmd_gemm", 0, 0, K, ncols, hi_ - lo_, 1.0, ptr(gstrip[:, lo_:]), Rc, ptr(right[lo_:]), ld_right, 0.0,
+                                 ptr(part), ncols)
+                    dist.all_reduce(part)
+                    GM[Rt:Rt + K, :ncols] = part
 
             chol_ok = False
             if orthogonalizer in ("auto", "cholesky"):
