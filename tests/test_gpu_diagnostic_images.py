@@ -56,8 +56,8 @@ def test_chunked_streaming_and_inputs(gpu_ctx, monkeypatch):
     full = DI.make_correlation_image(mov, ctx=gpu_ctx)
     full_ac = DI.make_autocorrelation_image(mov, lag=2, ctx=gpu_ctx)
     monkeypatch.setattr(DI, "CHUNK_BYTES", 4 * 20 * 22 * 97)      # 97-frame chunks
-    np.testing.assert_allclose(DI.make_correlation_image(torch.from_numpy(mov).to(gpu_ctx.device), ctx=gpu_ctx), full, rtol=1e-9, atol=1e-9)
-    np.testing.assert_allclose(DI.make_autocorrelation_image(mov, lag=2, ctx=gpu_ctx), full_ac, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(DI.make_correlation_image(torch.from_numpy(mov).to(gpu_ctx.device), ctx=gpu_ctx), full, rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(DI.make_autocorrelation_image(mov, lag=2, ctx=gpu_ctx), full_ac, rtol=2e-5, atol=1e-6)
     np.random.seed(0)
     arr = localmd_amd.localmd_decomposition(mov, (20, 20), 600, max_components=4, background_rank=1, seed=3, sim_iters=5, ctx=gpu_ctx)
     dense = np.asarray(arr[:, :, :], dtype=np.float32)
