@@ -219,9 +219,22 @@ def run_config(ctx, name, arbiter=False, single=False, out=print, movie_seed=0):
     results, measures, prb = {}, {}, {}
 
     def oracle(label, precision=None, lapack="double"):
+        import sys
+        import threading
+
         t1 = time.perf_counter()
         O.LAPACK_PRECISION = lapack
         np.random.seed(7)
+        # a long oracle run prints nothing for minutes: a heartbeat on the real stdout keeps job watchdogs informed
+        stop = threading.Event()
+
+        def beat():
+            while not stop.wait(60.0):
+                sys.__stdout__.write(f"[{label}: {time.perf_counter() - t1:.0f} s ...]\n")
+                sys.__stdout__.flush()
+
+        hb = threading.Thread(target=beat, daemon=True)
+        hb.start()
         try:
             if precision == "fp64":
                 with O.arbiter_precision():
@@ -231,6 +244,7 @@ def run_config(ctx, name, arbiter=False, single=False, out=print, movie_seed=0):
                 res = O.localmd_decomposition(mov, c["block"], c["frames"], rng=DeviceSource(ctx, 123), thresholds=diag["thresholds"], **c["kw"])
         finally:
             O.LAPACK_PRECISION = "double"
+            stop.set()
         out(f"{label}: {time.perf_counter() - t1:.1f} s, rank before {res.diag['rank_before']} -> after {len(res.s)}")
         results[label] = res
         return res
