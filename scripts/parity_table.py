@@ -11,6 +11,7 @@ from localmd_amd._lib import Context
 
 if __name__ == "__main__":
     ctx = Context(0)
-    PM.run_config(ctx, sys.argv[1], arbiter="arbiter" in sys.argv[2:], single="single" in sys.argv[2:],
-                  out=lambda ln: print(ln, flush=True))
+    only = "arbiter-only" in sys.argv[2:]   # HIP against the float64 arbiter alone (the headline regime: each oracle run takes minutes)
+    PM.run_config(ctx, sys.argv[1], arbiter=only or "arbiter" in sys.argv[2:], single="single" in sys.argv[2:],
+                  out=lambda ln: print(ln, flush=True), fp32_oracle=not only)
     ctx.close()

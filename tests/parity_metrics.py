@@ -192,7 +192,7 @@ CONFIGS = {
 }
 
 
-def run_config(ctx, name, arbiter=False, single=False, out=print, movie_seed=0):
+def run_config(ctx, name, arbiter=False, single=False, out=print, movie_seed=0, fp32_oracle=True):
     """Runs the HIP path and the oracle(s) on one configuration; returns {"hip": (pmd, diag), "results": {label: oracle
     result}, "measures": {"A vs B": measure dict}, "probes": {...}}.  `out` receives the report lines."""
     import time
@@ -259,12 +259,14 @@ def run_config(ctx, name, arbiter=False, single=False, out=print, movie_seed=0):
             out(ln)
         out(f"[{key}] reconstruction probes: {prb[key]:.2e} of the peak")
 
-    ref = oracle("oracle fp32")
-    mism = np.nonzero(diag["tile_ranks"] != ref.diag["tile_ranks"])[0]
-    out(f"tile ranks differing (HIP vs oracle fp32): {len(mism)} of {len(diag['tile_ranks'])} {list(mism[:10])}")
-    out(f"mean_img rel {np.abs(pmd.mean_img / ref.mean_img - 1).max():.2e}, std_img rel {np.abs(pmd.var_img / ref.std_img - 1).max():.2e}")
     hc = hip_cols(diag)
-    compare("HIP", pmd, diag["tile_ranks"], hc, "oracle fp32", ref)
+    mism = np.zeros(0, dtype=np.int64)
+    if fp32_oracle:
+        ref = oracle("oracle fp32")
+        mism = np.nonzero(diag["tile_ranks"] != ref.diag["tile_ranks"])[0]
+        out(f"tile ranks differing (HIP vs oracle fp32): {len(mism)} of {len(diag['tile_ranks'])} {list(mism[:10])}")
+        out(f"mean_img rel {np.abs(pmd.mean_img / ref.mean_img - 1).max():.2e}, std_img rel {np.abs(pmd.var_img / ref.std_img - 1).max():.2e}")
+        compare("HIP", pmd, diag["tile_ranks"], hc, "oracle fp32", ref)
     if single:
         ref1 = oracle("oracle fp32 single-LAPACK", lapack="single")
         compare("oracle fp32 single-LAPACK", ref1, ref1.diag["tile_ranks"], oracle_cols(ref1), "oracle fp32", ref)
