@@ -214,15 +214,24 @@ def main():
         "algorithmic_gb_per_launch": bytes_per_launch / 1e9,
         "hbm_gbs_equiv": bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0,
     }
-    # HBM-side traffic of the same launch from the committed PMC pass (profiles/r01_pmc_tile_atx.json: separate
-    # rocprofv3 --pmc FETCH_SIZE run, gfx950 x2 correction applied); only valid for the workload it was taken on
+    # HBM-side traffic of the same launch from the committed counter pass; valid for the workload it was taken on and while
+    # the kernel source is unchanged (SHA-256 recorded with the pass)
     try:
-        pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_tile_atx.json")))
-        if args.config == DEFAULT_CONFIG:
+        import hashlib
+
+        root = os.path.dirname(os.path.abspath(__file__))
+        pmc = json.load(open(os.path.join(root, "profiles", "r02_pmc_tile_atx.json")))
+        sha = hashlib.sha256(open(os.path.join(root, pmc["kernel_source"]), "rb").read()).hexdigest()
+        if args.config != DEFAULT_CONFIG:
+            roofline["traffic_note"] = "no counter pass for this workload"
+        elif sha != pmc["kernel_source_sha256"]:
+            roofline["traffic_note"] = "stale: the kernel source changed since the counter pass (profiles/r02_pmc_tile_atx.json)"
+        else:
             roofline["traffic"] = pmc["fetch_bytes_per_launch"] / 1e9
             roofline["traffic_unit"] = "GB per launch (L2 -> fabric reads, Infinity Cache hits included)"
+            roofline["traffic_source"] = "profiles/r02_pmc_tile_atx.json (separate rocprofv3 --pmc FETCH_SIZE pass, gfx950 x2 correction)"
     except (OSError, KeyError, ValueError):
-        pass
+        roofline["traffic_note"] = "no committed counter pass found"
     roofline_mfma = roofline
     # Dominant kernel by time: sytrd_symv (triangle matrix-vector product of the tridiagonalisation behind the
     # final SVD, one launch per column of the min(R', T)-sized Gram matrix).  Algorithmic bytes per launch =
@@ -245,14 +254,26 @@ def main():
         # fabric-side traffic of the same launches from the committed PMC pass (profiles/r01_pmc_sytrd_n10000.json:
         # separate rocprofv3 --pmc FETCH_SIZE run over one n = 10^4 tridiagonalisation, gfx950 x2 correction applied,
         # mean over the launches j = 32, 96, ... that are timed here); only valid for a matrix of that order
+        # A counter pass cannot run inside this process (rocprofv3 wraps the program), so the figure is the committed
+        # one - valid only for a matrix of that order AND while the kernel's source is the file it was measured on
+        # (SHA-256 recorded with the pass); otherwise `traffic` stays null and says why.
         try:
-            pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_sytrd_n10000.json")))
-            if abs(n_eig - pmc["matrix_order"]) <= 1:
+            import hashlib
+
+            root = os.path.dirname(os.path.abspath(__file__))
+            pmc = json.load(open(os.path.join(root, "profiles", "r02_pmc_sytrd_n10000.json")))
+            sha = hashlib.sha256(open(os.path.join(root, pmc["kernel_source"]), "rb").read()).hexdigest()
+            if abs(n_eig - pmc["matrix_order"]) > 1:
+                roofline["traffic_note"] = "no counter pass for a matrix of this order"
+            elif sha != pmc["kernel_source_sha256"]:
+                roofline["traffic_note"] = "stale: the kernel source changed since the counter pass (profiles/r02_pmc_sytrd_n10000.json)"
+            else:
                 roofline["traffic"] = pmc["traffic_bytes_per_launch_sample_mean"] / 1e9
                 roofline["traffic_unit"] = "GB per launch (L2 -> fabric reads, Infinity Cache hits included)"
                 roofline["traffic_over_algorithmic"] = pmc["traffic_over_algorithmic_sample"]
+                roofline["traffic_source"] = "profiles/r02_pmc_sytrd_n10000.json (separate rocprofv3 --pmc FETCH_SIZE pass, gfx950 x2 correction)"
         except (OSError, KeyError, ValueError):
-            pass
+            roofline["traffic_note"] = "no committed counter pass found"
     out = {
         "metric": "frames/sec PMD decomposition", "value": value, "unit": "frames/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,

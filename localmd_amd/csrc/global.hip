@@ -90,11 +90,70 @@ static int gemm_rm_split(pmd_ctx* ctx, int transA, int transB, int m, int n, int
   return PMD_OK;
 }
 
+// ---------------------------------------------------------------- long inner dimension ------
+// A product with few output tiles and a very long inner dimension (M^T G M and M^T Z when R = 3e5 tile components meet
+// 1e3 frames: 1000 x 1000 outputs, k = 3e5) leaves most CUs idle in rocBLAS' sgemm (measured 20 TFLOP/s on the many-tile
+// workloads).  The inner dimension is cut into S slices that run as ONE strided-batched sgemm (S x the workgroups) into
+// S partial outputs, which a second kernel sums in a fixed order (reproducible).
+__global__ void sum_partials_kernel(const float* __restrict__ part, long mn, int n, int S, float beta, float* __restrict__ C, long ldc) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < mn; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / n;
+    const int c = (int)(i - r * n);
+    float acc = 0.f;
+    for (int s = 0; s < S; ++s) acc += part[(long)s * mn + i];
+    float* o = C + r * ldc + c;
+    *o = (beta == 0.f) ? acc : acc + beta * *o;
+  }
+}
+
+static int gemm_rm_splitk(pmd_ctx* ctx, int transA, int transB, int m, int n, int k, int S, float alpha, const float* A, long lda,
+                          const float* B, long ldb, float beta, float* C, long ldc) {
+  pmd_prof_scope prof__(ctx, "rocblas_sgemm_splitk");
+  const int kc = (k + S - 1) / S;
+  const int full = k / kc, rem = k - full * kc;   // `full` slices of kc, one more of `rem`
+  const int slices = full + (rem ? 1 : 0);
+  const long mn = (long)m * n;
+  const size_t need = (size_t)slices * mn * sizeof(float) + 4096;
+  if (ctx->split_ws_bytes < need) {
+    PMD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->split_ws) (void)hipFree(ctx->split_ws);
+    ctx->split_ws = nullptr;
+    ctx->split_ws_bytes = 0;
+    PMD_HIP(ctx, hipMalloc(&ctx->split_ws, need));
+    ctx->split_ws_bytes = need;
+  }
+  float* part = (float*)ctx->split_ws;
+  const float zero = 0.f;
+  const rocblas_operation opA = transA ? rocblas_operation_transpose : rocblas_operation_none;
+  const rocblas_operation opB = transB ? rocblas_operation_transpose : rocblas_operation_none;
+  // slice s covers inner indices [s kc, (s + 1) kc): A advances by kc columns (or rows when transposed), B by kc rows (columns)
+  const long strideA = transA ? (long)kc * lda : kc, strideB = transB ? kc : (long)kc * ldb;
+  PMD_BLAS(ctx, rocblas_sgemm_strided_batched(ctx->blas, opB, opA, n, m, kc, &alpha, B, (rocblas_int)ldb, strideB, A, (rocblas_int)lda,
+                                              strideA, &zero, part, n, mn, full));
+  if (rem)
+    PMD_BLAS(ctx, rocblas_sgemm(ctx->blas, opB, opA, n, m, rem, &alpha, B + (long)full * strideB, (rocblas_int)ldb,
+                                A + (long)full * strideA, (rocblas_int)lda, &zero, part + (long)full * mn, n));
+  hipLaunchKernelGGL(sum_partials_kernel, dim3((unsigned)std::min<long>((mn + 255) / 256, 4096)), dim3(256), 0, ctx->stream, part, mn, n,
+                     slices, beta, C, ldc);
+  PMD_LAUNCH_CHECK(ctx, "sum_partials_kernel");
+  return PMD_OK;
+}
+
 int pmd_gemm_rm(pmd_ctx* ctx, int transA, int transB, int m, int n, int k, float alpha, const float* A, long lda,
                 const float* B, long ldb, float beta, float* C, long ldc) {
   if (m <= 0 || n <= 0) return PMD_OK;
   if (ctx->gemm_split && k > 0 && 2.0 * m * (double)n * k >= ctx->gemm_split_min_flop)
     return gemm_rm_split(ctx, transA, transB, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc);
+  {
+    // fewer than one 128 x 128 output tile per CU and an inner dimension that leaves >= 4096 per slice
+    static int mode = -1;   // PMD_GEMM_SPLITK=0 switches the path off (A/B runs)
+    if (mode < 0) { const char* e = getenv("PMD_GEMM_SPLITK"); mode = (e && !strcmp(e, "0")) ? 0 : 1; }
+    const long tiles = (long)((m + 127) / 128) * ((n + 127) / 128);
+    if (mode && tiles < 256 && k >= 16384) {
+      int S = (int)std::min<long>(std::min<long>(64, k / 4096), (512 + tiles - 1) / tiles);
+      if (S >= 2) return gemm_rm_splitk(ctx, transA, transB, m, n, k, S, alpha, A, lda, B, ldb, beta, C, ldc);
+    }
+  }
   pmd_prof_scope prof__(ctx, "rocblas_sgemm");
   PMD_BLAS(ctx, rocblas_sgemm(ctx->blas, transB ? rocblas_operation_transpose : rocblas_operation_none,
                               transA ? rocblas_operation_transpose : rocblas_operation_none, n, m, k, &alpha, B,

@@ -93,3 +93,46 @@ def test_headline_regime_parity(gpu_ctx):
     pmd, diag = res["hip"]
     assert diag["rank_before"] > diag["crop"] == 10000 and diag["orthogonalizer"] == "cholesky"
     _assert_common(res, u_tol=1e-3, s_sig=2e-3, vt_sig=3e-3, ur_sig=5e-2, r_sig=5e-1, probe_tol=1e-2, orth_tol=2e-2)
+
+
+def test_hip_path_reproduces_committed_golden_fixture(gpu_ctx):
+    """tests/golden/oracle_small.npz (written by tests/golden/make_golden.py from the oracle with the HOST Philox source,
+    seed 5) against the HIP path with the same seed: the device generator restates the same counter-based streams
+    (rng.hip; equal up to the rounding of logf / sincosf), so the committed vectors are reproduced without running the
+    oracle - tile ranks and CSR structure bit for bit, everything else to fp32 accuracy."""
+    import os
+    import scipy.sparse
+    import localmd_amd
+    from localmd_amd import decomposition as Dm
+    from localmd_amd.synthetic import make_movie
+    from tests.util import sign_align
+
+    Dm.QUIET = True
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_small.npz"), allow_pickle=False)
+    T, d1, d2 = (int(v) for v in g["movie_shape"])
+    mov = make_movie(T, d1, d2, seed=int(g["movie_seed"]))
+    np.random.seed(3)
+    pmd, diag = localmd_amd.localmd_decomposition(mov, (20, 16), 400, max_components=5, background_rank=2, seed=5,
+                                                  thresholds=tuple(g["thresholds"]), return_diagnostics=True, ctx=gpu_ctx)
+    np.testing.assert_array_equal(diag["tile_ranks"], g["tile_ranks"])
+    assert tuple(pmd.u.shape) == tuple(g["U_shape"])
+    np.testing.assert_array_equal(pmd.u.indptr, g["U_indptr"])
+    np.testing.assert_array_equal(pmd.u.indices, g["U_indices"])
+    np.testing.assert_allclose(pmd.mean_img, g["mean_img"], rtol=1e-5)
+    np.testing.assert_allclose(pmd.var_img, g["std_img"], rtol=2e-4)
+    assert pmd.s.shape == g["s"].shape and pmd.r.shape == g["R"].shape and pmd.v.shape == g["Vt"].shape
+    strong = g["s"] > 5e-2 * g["s"][0]
+    np.testing.assert_allclose(pmd.s[strong], g["s"][strong], rtol=2e-4)
+    # column signs of U are arbitrary per tile component: compare |U_data| where it is not tiny, and the reconstruction
+    big = np.abs(g["U_data"]) > 1e-2
+    np.testing.assert_allclose(np.abs(pmd.u.data[big]), np.abs(g["U_data"][big]), rtol=5e-3)
+    u_ref = scipy.sparse.csr_matrix((g["U_data"], g["U_indices"], g["U_indptr"]), shape=tuple(g["U_shape"]))
+    rng = np.random.default_rng(0)
+    pi, pt = rng.integers(0, d1 * d2, 500), rng.integers(0, T, 500)
+    rec = np.einsum("pk,k,kp->p", np.asarray(pmd.u[pi] @ pmd.r), pmd.s, pmd.v[:, pt])
+    rec0 = np.einsum("pk,k,kp->p", np.asarray(u_ref[pi] @ g["R"]), g["s"], g["Vt"][:, pt])
+    assert np.abs(rec - rec0).max() < 2e-3 * np.abs(rec0).max()
+    va = sign_align(pmd.v, g["Vt"], axis=1)
+    gaps = PM.rel_gaps(g["s"])
+    sig = strong & (gaps > PM.GAP)
+    assert np.linalg.norm(va[sig] - g["Vt"][sig]) / np.linalg.norm(g["Vt"][sig]) < 5e-4

@@ -548,3 +548,24 @@ def test_gemm_split_option(mode, monkeypatch):
             assert np.all(cd.cpu().numpy()[:, n:] == 0)
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 0), (1, 0), (0, 1), (1, 1)])
+def test_gemm_long_inner_dimension_split(gpu_ctx, ta, tb):
+    """pmd_gemm with few output tiles and a very long inner dimension takes the split-K path (strided-batched slices +
+    fixed-order sum, global.hip): same result as one product, for every operand orientation, beta != 0 and a ragged
+    last slice."""
+    torch = _t()
+    ctx = gpu_ctx
+    m, n, k = 200, 333, 70001
+    g = torch.Generator(device="cuda").manual_seed(ta * 2 + tb)
+    A = torch.randn((k, m) if ta else (m, k), device=ctx.device, generator=g)
+    B = torch.randn((n, k) if tb else (k, n), device=ctx.device, generator=g)
+    C0 = torch.randn((m, n + 5), device=ctx.device, generator=g)
+    C = C0.clone()
+    ctx.call("pmd_gemm", ta, tb, m, n, k, 0.5, P(A), A.shape[1], P(B), B.shape[1], 2.0, P(C), n + 5)
+    ctx.sync()
+    ref = 0.5 * ((A.T if ta else A).double() @ (B.T if tb else B).double()) + 2.0 * C0[:, :n].double()
+    err = (C[:, :n].double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 2e-6, err
+    assert torch.equal(C[:, n:], C0[:, n:])
