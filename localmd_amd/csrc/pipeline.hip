@@ -86,6 +86,11 @@ int pmd_tiles_decompose_impl(pmd_ctx* ctx, const float* Xf, long ldx, long n_row
   if (ar.overflow) return pmd_fail(ctx, PMD_ERR_WORKSPACE, "pmd_tiles_decompose", "workspace too small");
   if (r > p.nref) return pmd_fail(ctx, PMD_ERR_ARG, "pmd_tiles_decompose", "max_components exceeds pooled pixel count");
   const long s64d = 64L * p.dpad, s64P = 64L * p.Ppad, s64b = 64L * p.ld_b, s64v = 64L * ldv;
+  // PMD_TILE_WHITEN=eig restores the eigenvector form of the two pure orthonormalisation steps (A/B runs)
+  static int whiten_mode = -1;
+  if (whiten_mode < 0) { const char* e = getenv("PMD_TILE_WHITEN"); whiten_mode = (e && !strcmp(e, "eig")) ? 0 : 1; }
+  const bool whiten_chol = whiten_mode && stages == 7;   // the spatial_denoiser hook sees S = X V_b^T column by column
+  const bool whiten_chol_u0 = whiten_mode != 0;
 
   // stages: bit 0 = up to V_ds (p.outA; the temporal_denoiser hook of decomposition.py:300 acts on it),
   //         bit 1 = basis of its row space and S = X V_b^T (p.sst; spatial_denoiser hook, :310), bit 2 = the rest
@@ -117,7 +122,10 @@ int pmd_tiles_decompose_impl(pmd_ctx* ctx, const float* Xf, long ldx, long n_row
   // (this Gram only conditions the basis change -- span(S) does not depend on it -- so fp32 MFMA is enough)
   RUN(pmd_launch_tile_xbt(ctx, p.outA, ldv, nullptr, 0, 64, 64, p.outA, s64v, ldv, p.g1f, GRAM_SLICES * 4096L, 4096, 64, n, t_crop, GRAM_SLICES));
   RUN(pmd_launch_gram_f2d(ctx, p.g1f, 64, (long)n * GRAM_SLICES, p.gpart));
-  RUN(pmd_launch_small_eig(ctx, p.gpart, GRAM_SLICES, r, 1, 1e-10, p.nmat, p.lam, n));
+  // only span(S) matters downstream: with no denoiser hook reading S component by component (stages == 7) any orthonormal
+  // basis of the row space of V_ds serves, and the Cholesky whitening replaces the Jacobi eigensolver (small_la.hip)
+  if (whiten_chol) RUN(pmd_launch_small_chol(ctx, p.gpart, GRAM_SLICES, r, 1e-10, p.nmat, n));
+  else RUN(pmd_launch_small_eig(ctx, p.gpart, GRAM_SLICES, r, 1, 1e-10, p.nmat, p.lam, n));
 
   // --- S = X V_b^T and its left singular vectors U0 (decomposition.py:304-317)
   RUN(pmd_launch_tile_xbt(ctx, Xf, ldx, tile_pix, d, 0, d, p.outA, s64v, ldv, p.spart, XBT_SLICES * s64d, s64d, p.dpad, n, t_crop, XBT_SLICES));
@@ -126,7 +134,9 @@ int pmd_tiles_decompose_impl(pmd_ctx* ctx, const float* Xf, long ldx, long n_row
   }
   if (stages & 4) {
   RUN(pmd_launch_tile_gram(ctx, p.sst, s64d, p.dpad, d, n, 1, p.gpart));
-  RUN(pmd_launch_small_eig(ctx, p.gpart, 1, r, 1, 1e-10, p.nmat, p.lam, n));
+  // U = U0 Wl depends on span(U0) = span(S) only: an orthonormal basis of it is enough (always; no hook reads U0)
+  if (whiten_chol_u0) RUN(pmd_launch_small_chol(ctx, p.gpart, 1, r, 1e-10, p.nmat, n));
+  else RUN(pmd_launch_small_eig(ctx, p.gpart, 1, r, 1, 1e-10, p.nmat, p.lam, n));
   RUN(pmd_launch_tile_rowmix(ctx, p.sst, s64d, p.dpad, p.nmat, 4096, r, r, p.sst, s64d, p.dpad, d, n));
 
   // --- W = U0^T X, its SVD rotates U0 and gives sigma*V (decomposition.py:318-323)

@@ -46,6 +46,7 @@ int pmd_launch_small_qr(pmd_ctx* ctx, const float* Yt, long y_tile_stride, int y
                         long q_tile_stride, int q_ld, int n_tiles);
 int pmd_launch_small_eig(pmd_ctx* ctx, const double* G, int slices, int n, int mode, double tol, double* Nout,
                          double* lam_out, int n_tiles);
+int pmd_launch_small_chol(pmd_ctx* ctx, const double* G, int slices, int n, double tol, double* Nout, int n_tiles);
 int pmd_launch_expand_pooled(pmd_ctx* ctx, const float* In, long in_tile_stride, int in_ld, const int* pool_idx,
                              const float* pool_w, int d, int r, float* Out, long out_tile_stride, int out_ld,
                              int n_tiles);

@@ -134,10 +134,11 @@ int pmd_launch_small_qr(pmd_ctx* ctx, const float* Yt, long y_tile_stride, int y
 //   mode 1: column c scaled by 1/sqrt(lambda_c); columns with lambda_c <= tol*lambda_max zeroed
 // lam_out[tile][c] = eigenvalue c (descending); entries >= n are zero.
 #define EIG_LD 65
-// Threads per problem.  A problem holds 66.5 KB of LDS (A and V in fp64), so two share a CU whatever the workgroup
-// size; one rotation step is ~18 000 fp64 FMAs (A <- J^T A J and V <- V J at n = 60) between two barriers.  With 1024
-// threads (one 2 x 2 block each) the step is bound by the barriers of 16 waves and the LDS round trips; with 256
-// threads a wave keeps four blocks in flight and the barrier joins four waves (measured: PMD_EIG_THREADS=256|512|1024).
+// Threads per problem (PMD_EIG_THREADS=256|512|1024, default 1024).  A problem holds 66.5 KB of LDS (A and V in fp64), so
+// two share a CU whatever the workgroup size; one rotation step is ~18 000 fp64 FMAs (A <- J^T A J and V <- V J at
+// n = 60) between two barriers.  Measured (round 2, 16 129 tiles x 4 launches): 83 / 96 / 130 ms per step with 1024 /
+// 512 / 256 threads - the step is bound by its chain of dependent LDS round trips, which more threads shorten, not by
+// the fp64 rate.
 template <int EIG_THREADS>
 __global__ __launch_bounds__(EIG_THREADS) void small_eig_kernel(const double* __restrict__ G, long g_tile_stride, int slices,
                                                         int n, int mode, double tol, double* __restrict__ Nout,
@@ -268,8 +269,8 @@ int pmd_launch_small_eig(pmd_ctx* ctx, const double* G, int slices, int n, int m
   static int threads = 0;
   if (!threads) {
     const char* e = getenv("PMD_EIG_THREADS");
-    threads = e ? atoi(e) : 256;
-    if (threads != 256 && threads != 512 && threads != 1024) threads = 256;
+    threads = e ? atoi(e) : 1024;
+    if (threads != 256 && threads != 512 && threads != 1024) threads = 1024;
   }
 #define PMD_EIG_LAUNCH(TH)                                                                                                      \
   do {                                                                                                                          \
@@ -279,9 +280,76 @@ int pmd_launch_small_eig(pmd_ctx* ctx, const double* G, int slices, int n, int m
   } while (0)
   if (threads == 1024) PMD_EIG_LAUNCH(1024);
   else if (threads == 512) PMD_EIG_LAUNCH(512);
-  else PMD_EIG_LAUNCH(256);
+  else PMD_EIG_LAUNCH(256);  // 83 / 96 / 130 ms per step with 1024 / 512 / 256 threads on the 16 129-tile workload: latency, not fp64 rate, bounds a step
 #undef PMD_EIG_LAUNCH
   PMD_LAUNCH_CHECK(ctx, "small_eig_kernel");
+  return PMD_OK;
+}
+
+// ---------------------------------------------------------------- batched Cholesky whitening
+// Same interface as small_eig mode 1 where only an ORTHONORMAL BASIS is wanted, not the eigenvectors: G = R^T R
+// (upper R), Nout[tile][c'][c] = (R^{-1})[c'][c], so that tile_rowmix turns rows with Gram matrix G into orthonormal
+// rows (new row c = sum_c' N[c'][c] old row c').  A pivot <= tol * max diagonal marks a direction that depends on the
+// earlier ones: its column is zero (the counterpart of small_eig's lambda <= tol * lambda_max).  One wave per problem,
+// ~50 us against ~0.7 ms for the Jacobi solver: two of the four factorisations of single_block_md
+// (decomposition.py:301, :315-317) only feed spans - span(S) does not depend on the basis of the row space of V_ds, and
+// U = U0 Wl does not depend on the basis U0 of span(S) - and take this path when no denoiser hook reads the vectors.
+__global__ __launch_bounds__(64) void small_chol_kernel(const double* __restrict__ G, long g_tile_stride, int slices, int n,
+                                                        double tol, double* __restrict__ Nout) {
+  __shared__ double R[64][65];
+  __shared__ double Ri[64][65];
+  __shared__ int dead[64];
+  const int t = threadIdx.x;
+  const double* g = G + (long)blockIdx.x * g_tile_stride;
+  for (int i = 0; i < 64; ++i) {
+    double s = 0.0;
+    if (i < n && t < n)
+      for (int k = 0; k < slices; ++k) s += g[(long)k * 4096 + i * 64 + t] + g[(long)k * 4096 + t * 64 + i];
+    R[i][t] = 0.5 * s;
+    Ri[i][t] = 0.0;
+  }
+  __syncthreads();
+  double dmax = 0.0;
+  for (int i = 0; i < n; ++i) dmax = fmax(dmax, R[i][i]);
+  // right-looking Cholesky, upper factor stored in R (row k = R[k][k:])
+  for (int k = 0; k < n; ++k) {
+    const double piv = R[k][k];
+    const bool bad = !(piv > tol * dmax);
+    if (t == 0) dead[k] = bad;
+    const double rkk = bad ? 1.0 : sqrt(piv);
+    double rkt = 0.0;
+    if (t >= k && t < n) rkt = bad ? ((t == k) ? 1.0 : 0.0) : R[k][t] / rkk;
+    __syncthreads();
+    if (t >= k && t < n) R[k][t] = rkt;
+    __syncthreads();
+    // trailing update: R[i][j] -= R[k][i] * R[k][j], i, j > k; thread t owns column j = t
+    if (!bad && t > k && t < n)
+      for (int i = k + 1; i <= t; ++i) R[i][t] -= R[k][i] * rkt;
+    __syncthreads();
+  }
+  // invert the upper-triangular factor: thread t solves column t of R X = I
+  if (t < n) {
+    for (int i = t; i >= 0; --i) {
+      double s = (i == t) ? 1.0 : 0.0;
+      for (int j = i + 1; j <= t; ++j) s -= R[i][j] * Ri[j][t];
+      Ri[i][t] = s / R[i][i];
+    }
+  }
+  __syncthreads();
+  double* no = Nout + (long)blockIdx.x * 4096;
+  for (int i = 0; i < 64; ++i) {
+    double v = (i < n && t < n) ? Ri[i][t] : 0.0;
+    if (t < n && dead[t]) v = 0.0;
+    no[i * 64 + t] = v;
+  }
+}
+
+int pmd_launch_small_chol(pmd_ctx* ctx, const double* G, int slices, int n, double tol, double* Nout, int n_tiles) {
+  pmd_prof_scope prof__(ctx, "small_chol");
+  if (n_tiles <= 0) return PMD_OK;
+  if (n > 64 || n < 1) return pmd_fail(ctx, PMD_ERR_UNSUPPORTED, "small_chol", "n must be in [1, 64]");
+  hipLaunchKernelGGL(small_chol_kernel, dim3(n_tiles), dim3(64), 0, ctx->stream, G, (long)slices * 4096, slices, n, tol, Nout);
+  PMD_LAUNCH_CHECK(ctx, "small_chol_kernel");
   return PMD_OK;
 }
 
