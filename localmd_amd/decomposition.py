@@ -112,7 +112,8 @@ class _Movie:
     # on a copy stream, so decoding batch k + 1 overlaps the transfer of batch k; a buffer is reused once the event
     # recorded behind its transfer has completed.
     STAGE_BUFFERS = 3
-    STAGE_BYTES = 256 << 20
+    STAGE_BYTES = 64 << 20
+    _stage_cache = {}     # (frames per buffer, D, pinned) -> ring of staging buffers, kept between calls (page-locking is slow)
 
     def _stream_in(self, dataset_obj, frame_batch_size, i_lo, i_hi, num_workers):
         torch = _torch()
@@ -121,10 +122,14 @@ class _Movie:
         on_gpu = self.ctx.device.type == "cuda"
         frame_bytes = 4 * self.D
         step = max(1, min(int(frame_batch_size), self.STAGE_BYTES // max(frame_bytes, 1), self.T))
-        n_threads = int(num_workers) if num_workers and num_workers > 0 else min(8, os.cpu_count() or 1)
+        n_threads = int(num_workers) if num_workers and num_workers > 0 else min(32, os.cpu_count() or 1)
         is_array = isinstance(dataset_obj, np.ndarray)
         full_rows = (i_lo == 0 and i_hi == self.d1)
-        stage = [torch.empty((step, self.D), dtype=torch.float32, pin_memory=on_gpu) for _ in range(self.STAGE_BUFFERS)]
+        key = (step, self.D, on_gpu)
+        if key not in _Movie._stage_cache:
+            _Movie._stage_cache.clear()
+            _Movie._stage_cache[key] = [torch.empty((step, self.D), dtype=torch.float32, pin_memory=on_gpu) for _ in range(self.STAGE_BUFFERS)]
+        stage = _Movie._stage_cache[key]
         stage_np = [b.numpy() for b in stage]
         done = [None] * self.STAGE_BUFFERS
         copy_stream = _side_stream(self.ctx.device) if on_gpu else None
