@@ -9,11 +9,11 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --kernel-trace --stats -d "$OUT/bench" -o bench -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-host-input > "$OUT/bench_line.json" 2> "$OUT/bench.err" || echo "bench profile failed" >&2
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/bench" -o bench -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline --no-host-input > "$OUT/bench_line.json" 2> "$OUT/bench.err" || echo "bench profile failed" >&2
 echo "[profile] bench trace done"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --kernel-include-regex sytrd_symv -d "$OUT/pmc_sytrd" -o pmc -- python3 "$ROOT/scripts/sytrd_prof.py" 10000 1 1 > "$OUT/pmc_sytrd.log" 2>&1 || echo "sytrd pmc failed" >&2
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv --kernel-include-regex sytrd_symv -d "$OUT/pmc_sytrd" -o pmc -- python3 "$ROOT/scripts/sytrd_prof.py" 10000 1 1 > "$OUT/pmc_sytrd.log" 2>&1 || echo "sytrd pmc failed" >&2
 echo "[profile] sytrd counter pass done"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --kernel-include-regex tile_atx -d "$OUT/pmc_atx" -o pmc -- python3 "$ROOT/scripts/atx_pmc.py" > "$OUT/pmc_atx.log" 2>&1 || echo "atx pmc failed" >&2
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv --kernel-include-regex tile_atx -d "$OUT/pmc_atx" -o pmc -- python3 "$ROOT/scripts/atx_pmc.py" > "$OUT/pmc_atx.log" 2>&1 || echo "atx pmc failed" >&2
 echo "[profile] atx counter pass done"
 cd "$ROOT"
 CSV=$(find "$OUT/pmc_sytrd" -name "*counter_collection.csv" | head -1)
