@@ -640,21 +640,28 @@ __global__ void reduce_slices_kernel(const float* __restrict__ in, long tile_str
   }
 }
 
-// the same with 16-byte accesses and four quads per thread: a quarter of the loads and 1/16 of the workgroups (with one
-// element per thread and 256-element workgroups the pass ran at 0.33 TB/s on 16 129 tiles: bound by workgroup dispatch)
+// the same with 16-byte accesses, one quad per thread, all slice loads of a thread issued before the first add
+// (four quads per thread in a loop was 2.2x SLOWER than the scalar kernel: each iteration waited for its own loads)
 __global__ __launch_bounds__(256) void reduce_slices4_kernel(const float4* __restrict__ in, long tile_stride4, long slice_stride4,
                                                              int slices, long n4, float4* __restrict__ out, long out_tile_stride4) {
   const int tile = blockIdx.y;
-  const float4* src = in + (long)tile * tile_stride4;
-  float4* dst = out + (long)tile * out_tile_stride4;
-  for (long i = (long)blockIdx.x * 1024 + threadIdx.x; i < n4 && i < ((long)blockIdx.x + 1) * 1024; i += 256) {
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const float4* src = in + (long)tile * tile_stride4 + i;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  if (slices == 4) {
+    const float4 a = src[0], b = src[slice_stride4], c = src[2 * slice_stride4], d = src[3 * slice_stride4];
+    s0 = (double)a.x + (double)b.x + (double)c.x + (double)d.x;
+    s1 = (double)a.y + (double)b.y + (double)c.y + (double)d.y;
+    s2 = (double)a.z + (double)b.z + (double)c.z + (double)d.z;
+    s3 = (double)a.w + (double)b.w + (double)c.w + (double)d.w;
+  } else {
     for (int k = 0; k < slices; ++k) {
-      const float4 v = src[(long)k * slice_stride4 + i];
+      const float4 v = src[(long)k * slice_stride4];
       s0 += (double)v.x; s1 += (double)v.y; s2 += (double)v.z; s3 += (double)v.w;
     }
-    dst[i] = make_float4((float)s0, (float)s1, (float)s2, (float)s3);
   }
+  out[(long)tile * out_tile_stride4 + i] = make_float4((float)s0, (float)s1, (float)s2, (float)s3);
 }
 
 int pmd_launch_reduce_slices(pmd_ctx* ctx, const float* in, long tile_stride, long slice_stride, int slices, long n,
@@ -663,7 +670,7 @@ int pmd_launch_reduce_slices(pmd_ctx* ctx, const float* in, long tile_stride, lo
   if (n % 4 == 0 && tile_stride % 4 == 0 && slice_stride % 4 == 0 && out_tile_stride % 4 == 0 && !((uintptr_t)in & 15) &&
       !((uintptr_t)out & 15)) {
     const long n4 = n / 4;
-    const unsigned bx4 = (unsigned)((n4 + 1023) / 1024);
+    const unsigned bx4 = (unsigned)((n4 + 255) / 256);
     for (int t0 = 0; t0 < n_tiles; t0 += 32768) {
       const int tn = (n_tiles - t0 < 32768) ? n_tiles - t0 : 32768;
       hipLaunchKernelGGL(reduce_slices4_kernel, dim3(bx4, tn), dim3(256), 0, ctx->stream,
