@@ -134,6 +134,7 @@ class _Movie:
         done = [None] * self.STAGE_BUFFERS
         copy_stream = _side_stream(self.ctx.device) if on_gpu else None
         if on_gpu:
+            copy_stream.synchronize()     # the staging ring is kept between calls: no transfer of an earlier call may still read it
             copy_stream.wait_stream(torch.cuda.current_stream(self.ctx.device))   # self.dev may reuse a block still in use
 
         def fill(buf, t0, t1):

@@ -12,7 +12,9 @@ from localmd_amd import decomposition as Dm
 from localmd_amd.synthetic import make_movie
 Dm.QUIET = True
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-dist.init_process_group("gloo")
+import datetime
+# a stuck collective raises after three minutes instead of waiting for gloo's default half hour
+dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=180))
 rank = dist.get_rank()
 ok_all = True
 cases = [

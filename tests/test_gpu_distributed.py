@@ -26,10 +26,19 @@ def _free_port():
 
 @pytest.mark.parametrize("world", [2, 3])
 def test_distributed_matches_single_rank(gpu_ctx, world):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONUNBUFFERED="1", PYTHONFAULTHANDLER="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "scripts", "dist_check.py")]
-    out = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
-    print(out.stdout[-6000:])
-    assert out.returncode == 0, out.stdout[-3000:]
-    assert out.stdout.count("ok=True") == 6 * world and "ok=False" not in out.stdout
+    # own process group + a hard limit: a rank that dies or a stuck collective must fail this test, not stall the suite
+    proc = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, start_new_session=True)
+    try:
+        stdout, _ = proc.communicate(timeout=300)
+    except subprocess.TimeoutExpired:
+        import signal
+
+        os.killpg(proc.pid, signal.SIGKILL)
+        stdout, _ = proc.communicate()
+        pytest.fail("distributed run did not finish within 300 s:\n" + stdout[-4000:])
+    print(stdout[-6000:])
+    assert proc.returncode == 0, stdout[-3000:]
+    assert stdout.count("ok=True") == 6 * world and "ok=False" not in stdout
