@@ -29,6 +29,10 @@ CONFIGS = {
     "1024x1024x8000_b32": dict(T=8000, d1=1024, d2=1024, block=32, frames=8000, max_components=50),
     # block / overlap of BASELINE config 5 on a quarter of its field of view
     "1024x1024x1000_b16": dict(T=1000, d1=1024, d2=1024, block=16, frames=1000, max_components=50),
+    # BASELINE configs 4 and 5 at full size (84 GB movies) on ONE GPU: the single-copy memory plan and the tile batches
+    # of localmd_decomposition keep them inside 288 GB (BASELINE.json quotes them on 8 GPUs; no such node was available)
+    "1024x1024x20000_b32": dict(T=20000, d1=1024, d2=1024, block=32, frames=20000, max_components=50),
+    "2048x2048x5000_b16": dict(T=5000, d1=2048, d2=2048, block=16, frames=5000, max_components=50),
 }
 DEFAULT_CONFIG = "512x512x10000_b20"
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, dense f32 matrix peak

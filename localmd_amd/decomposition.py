@@ -94,12 +94,14 @@ class _Movie:
         self.T, self.d1, self.d2 = shape
         i_lo, i_hi = (0, self.d1) if rows is None else rows
         self.D = (i_hi - i_lo) * self.d2
+        self.owned = True    # False: self.dev aliases the caller's tensor (releasing it frees nothing)
         if hasattr(dataset_obj, "slab"):   # a source that can build a band of FOV rows on the device
             mv = dataset_obj.slab(i_lo, i_hi).to(device=ctx.device, dtype=torch.float32)
             self.dev = mv.reshape(self.T, self.D).contiguous()
         elif isinstance(dataset_obj, torch.Tensor):
             mv = dataset_obj[:, i_lo:i_hi, :].to(device=ctx.device, dtype=torch.float32)
             self.dev = mv.reshape(self.T, self.D).contiguous()
+            self.owned = self.dev.data_ptr() != dataset_obj.data_ptr()
         else:
             self.dev = torch.empty((self.T, self.D), dtype=torch.float32, device=ctx.device)
             self._stream_in(dataset_obj, frame_batch_size, i_lo, i_hi, num_workers)
@@ -169,6 +171,11 @@ class _Movie:
                     self.dev[base:base + n].copy_(stage[buf][:n])
         if on_gpu:
             torch.cuda.current_stream(self.ctx.device).wait_stream(copy_stream)
+
+    def release(self):
+        """Drop the raw frames-first copy once every standardised copy has been written (statistics, the background
+        sample and the standardised movies are its only readers): 1/3 of the resident bytes of a large movie."""
+        self.dev = None
 
     def standardized(self, frames, mean, std):
         """Pixel-major (rows_alloc x ld) standardised frames; frames=None means all, in order."""
@@ -389,6 +396,8 @@ def localmd_decomposition(
     orthogonalizer: str = "auto",
     null_directions: str = "keep",
     null_cutoff: float = 0.0,
+    single_copy: Optional[bool] = None,
+    tile_batch_bytes: int = 24 << 30,
     distributed: bool = False,
     return_diagnostics: bool = False,
     ctx: Optional[Context] = None,
@@ -538,6 +547,16 @@ def localmd_decomposition(
         else:
             xs_init, ld_f = movie.standardized(frames, mean_dev, std_dev)
         pj_dev = None
+        movie.release()      # the standardised copies are written: the raw frames are not read again
+        # Memory plan for movies that fill the HBM (BASELINE configs 4 / 5: 84 GB): with every frame fitted the filtered
+        # copy X_f = X - B (B^T X) replaces the standardised one in place, and the movie projection of the last stage is
+        # formed as (UW)^T X = (UW)^T X_f + ((UW)^T B) (B^T X) - the second term is a rank-K product of quantities the
+        # global stage holds anyway (the background strip of U^T U, the background traces).  One movie-sized array
+        # instead of two (three with the raw copy).  `single_copy=None`: automatic, above 1/8 of the device memory.
+        Tf_, Ta_ = len(frames), (len(frames) // int(temporal_avg_factor)) * int(temporal_avg_factor)
+        if single_copy is None:
+            single_copy = 4.0 * Dl * T > torch.cuda.get_device_properties(ctx.device).total_memory / 8.0
+        single_copy = bool(single_copy) and all_frames and K > 0 and pixel_weighting is None and Ta_ == Tf_
         if K > 0:
             pj_dev = torch.zeros((K, ld_f), dtype=torch.float32, device=ctx.device)
             # projection on the background basis: a sum over pixels - owned pixels here, summed over the ranks
@@ -545,10 +564,16 @@ def localmd_decomposition(
             ctx.call("pmd_bg_project", ptr(xs_init[O_lo - P_lo:]), O_hi - O_lo, Tf, ld_f, ptr(basis_dev[O_lo:]), K, ptr(pj_dev),
                      ld_f, ptr(ws), ws.numel())
             dist.all_reduce(pj_dev)
-            xf = torch.empty_like(xs_init)   # bg_filter writes all ld columns of the resident pixel rows
-            if xf.shape[0] > Dl:
-                xf[Dl:].zero_()
+            if single_copy:
+                xf = xs_init                     # filtered in place (the kernel is element-wise)
+                xs_full = None
+            else:
+                xf = torch.empty_like(xs_init)   # bg_filter writes all ld columns of the resident pixel rows
+                if xf.shape[0] > Dl:
+                    xf[Dl:].zero_()
             ctx.call("pmd_bg_filter", ptr(xs_init), ptr(xf), Dl, Tf, ld_f, ptr(basis_dev[P_lo:]), K, ptr(pj_dev), ld_f)
+            if single_copy:
+                xs_init = None
         else:
             xf = xs_init.clone() if pixel_weighting is not None else xs_init
         if pixel_weighting is not None:
@@ -580,7 +605,7 @@ def localmd_decomposition(
             # kernels walk the time axis in 32-frame chunks relying on zeros behind the last frame they are given:
             # frames crop .. Tf - 1 of the filtered copy must not leak into the contractions.  (Found by the seeded
             # fuzz of round 2: every draw with frames % temporal_avg_factor != 0 was off by ~1e-3 in its tile bases.)
-            if xf.data_ptr() == xs_init.data_ptr():
+            if xs_init is not None and xf.data_ptr() == xs_init.data_ptr():
                 xf = xs_init.clone()    # xs_init may be the standardised movie the V projection still needs
             xf[:, crop:Tf].zero_()
         pix_c, origins = grid.tile_pixel_lists((d1, d2), block_sizes, dim_1_iters, dim_2_iters)
@@ -599,7 +624,6 @@ def localmd_decomposition(
         r = int(max_components)
         ldv = ld_f
         ut_dev = torch.empty((n_tiles, 64, dpad), dtype=torch.float32, device=ctx.device)
-        v_dev = torch.empty((n_tiles, 64, ldv), dtype=torch.float32, device=ctx.device)
         stats_dev = torch.zeros((n_tiles, 64, 2), dtype=torch.float32, device=ctx.device)
         good_dev = torch.zeros((n_tiles, 64), dtype=torch.int32, device=ctx.device)
         keep_dev = torch.zeros((n_tiles, 64), dtype=torch.int32, device=ctx.device)
@@ -620,14 +644,42 @@ def localmd_decomposition(
             sim_pending = None
         thr_s32, thr_t32 = float(np.float32(spatial_threshold)), float(np.float32(temporal_threshold))
         a_f = int(temporal_avg_factor)
-        if n_loc > 0 and n_win == 1:
+        # Tile batches.  The per-tile temporaries ([tile][64][frames] traces and the kernels' workspace, ~3 such arrays)
+        # grow with tiles x frames: 84 GB each at BASELINE config 5 (65 025 tiles x 5 000 frames).  Above
+        # `tile_batch_bytes` the tiles are fitted (and later projected) in batches whose traces are compacted to the
+        # kept components right away; one batch (every workload up to config 3's size) is the single-launch path.
+        per_tile_bytes = 3 * 64 * int(max(ldv, ld_T)) * 4 + 8 * 64 * dpad * 4
+        tile_batch = max(8, int(tile_batch_bytes // per_tile_bytes))
+        batches = [(b0, min(n_loc, b0 + tile_batch)) for b0 in range(0, max(n_loc, 1), tile_batch)] if n_win == 1 else [(0, n_loc)]
+        batched = len(batches) > 1
+        v_dev = None if batched else torch.empty((n_tiles, 64, ldv), dtype=torch.float32, device=ctx.device)
+        v_pieces = []
+
+        def tiles_args(g0, nb_, v_out):
+            # g0: global index of the batch's first tile (the Gaussian matrix of a tile is keyed by it)
+            return (ptr(xf), ld_f, Dl, crop, ptr(pix_loc_dev[g0 - t_lo:]), nb_, b1, b2, ptr(pool_q_dev), pool_q.shape[1], P_pool,
+                    ptr(pool_idx_dev), ptr(pool_w_dev), r, a_f, thr_s32, thr_t32, int(max_consecutive_failures), seed, g0, 1,
+                    ptr(ut_dev[g0:]), ptr(v_out), ldv, ptr(stats_dev[g0:]), ptr(good_dev[g0:]), ptr(keep_dev[g0:]),
+                    ptr(ranks_dev[g0:]), ptr(lam_dev[g0:]))
+
+        if n_loc > 0 and n_win == 1 and not batched:
             ws = ctx.workspace(lib.pmd_tiles_workspace_bytes(n_loc, b1, b2, P_pool, r, a_f, crop, ldv, Dl))
-            _tiles_decompose(ctx, (ptr(xf), ld_f, Dl, crop, ptr(pix_loc_dev), n_loc, b1, b2, ptr(pool_q_dev),
-                                   pool_q.shape[1], P_pool, ptr(pool_idx_dev), ptr(pool_w_dev), r, a_f, thr_s32, thr_t32,
-                                   int(max_consecutive_failures), seed, t_lo, 1, ptr(ut_dev[t_lo:]), ptr(v_dev[t_lo:]), ldv,
-                                   ptr(stats_dev[t_lo:]), ptr(good_dev[t_lo:]), ptr(keep_dev[t_lo:]), ptr(ranks_dev[t_lo:]),
-                                   ptr(lam_dev[t_lo:])), ws, (n_loc, b1, b2, P_pool, r, a_f, crop, ldv, Dl, dpad),
+            _tiles_decompose(ctx, tiles_args(t_lo, n_loc, v_dev[t_lo:]), ws, (n_loc, b1, b2, P_pool, r, a_f, crop, ldv, Dl, dpad),
                              temporal_denoiser, spatial_denoiser)
+        elif n_loc > 0 and n_win == 1:
+            for b0, b1_ in batches:
+                nb_, g0 = b1_ - b0, t_lo + b0
+                vb = torch.empty((nb_, 64, ldv), dtype=torch.float32, device=ctx.device)
+                ws = ctx.workspace(lib.pmd_tiles_workspace_bytes(nb_, b1, b2, P_pool, r, a_f, crop, ldv, Dl))
+                _tiles_decompose(ctx, tiles_args(g0, nb_, vb), ws, (nb_, b1, b2, P_pool, r, a_f, crop, ldv, Dl, dpad),
+                                 temporal_denoiser, spatial_denoiser)
+                rk = ranks_dev[g0:g0 + nb_]
+                off_b = (torch.cumsum(rk, 0) - rk).to(torch.int32)
+                rows_b = int(rk.sum().item())
+                piece = torch.zeros((max(rows_b, 1), crop), dtype=torch.float32, device=ctx.device)
+                ctx.call("pmd_compact_rows", ptr(vb), ldv, ptr(off_b), ptr(rk), crop, ptr(piece), crop, nb_)
+                v_pieces.append(piece[:rows_b])
+                del vb
         elif n_loc > 0:
             # several windows: first window = single_block_md, later ones fit the residual (decomposition.py:471-515);
             # the Gaussian matrix of (tile, window) is logical array tile * n_win + window
@@ -669,7 +721,7 @@ def localmd_decomposition(
         inv_cumw_host = np.ascontiguousarray(1.0 / cumw.reshape(-1))
         ctx.sync()
         lap("tiles", t0)
-        _dbg("ut", ut_dev); _dbg("v_tiles", v_dev[:, :, :crop]); _dbg("tile_lambda", lam_dev)
+        _dbg("ut", ut_dev); _dbg("tile_lambda", lam_dev)
 
         # ---- sparse assembly (decomposition.py:752-857): CSR arrays built on the device
         t0 = time.perf_counter()
@@ -744,7 +796,13 @@ def localmd_decomposition(
         # v_cropped = [tile traces ; background temporal basis] (decomposition.py:844, :932)
         m_cols = crop
         vc = torch.zeros((Rc, m_cols), dtype=torch.float32, device=ctx.device)
-        if n_loc > 0:
+        if n_loc > 0 and batched:
+            row = int(offsets[t_lo])
+            for piece in v_pieces:
+                vc[row:row + piece.shape[0]] = piece
+                row += piece.shape[0]
+            v_pieces = None
+        elif n_loc > 0:
             ctx.call("pmd_compact_rows", ptr(v_dev[t_lo:]), ldv, ptr(col_off_dev[t_lo:]), ptr(ranks_dev[t_lo:]), crop, ptr(vc),
                      m_cols, n_loc)
         row_bounds = [(int(offsets[lo]), int(offsets[hi])) for lo, hi in runs]
@@ -787,22 +845,38 @@ def localmd_decomposition(
         shard = False               # rows of right / GM / Z / R split over the ranks (Cholesky route only)
         row_lo, row_hi = 0, Rc
         Z = W1 = None
+        bg_strip = None             # (K x Rc) background rows of U^T U (single-copy plan: the rank-K term of the projection)
 
         def build_z(everywhere):
             """Z = (U W)^T ((Y - mean) / std) over the whole movie (pmd_loader.py:316-346).  A rank projects the tiles
             of its own run (it holds no other pixels); everywhere=True then collects all rows on every rank (the
             replicated global stage), otherwise a rank keeps only its own rows (row-sharded stage).  The K
             background rows are filled on every rank."""
-            if all_frames and ldv == ld_T:
-                proj = v_dev     # same shape; the fit-frame traces are already compacted into v_cropped
-            else:
-                proj = torch.empty((n_tiles, 64, ld_T), dtype=torch.float32, device=ctx.device)
+            src = xf if xs_full is None else xs_full   # single-copy plan: the filtered movie + the rank-K term below
             z = torch.zeros((Rc, T), dtype=torch.float32, device=ctx.device)
-            if n_loc > 0:
-                ctx.call("pmd_tiles_project", ptr(xs_full), ld_T, T, ptr(pix_loc_dev), n_loc, d, ptr(uw_dev[t_lo:]), dpad,
+            if n_loc > 0 and batched:
+                for b0, b1_ in batches:
+                    nb_, g0 = b1_ - b0, t_lo + b0
+                    proj = torch.empty((nb_, 64, ld_T), dtype=torch.float32, device=ctx.device)
+                    ctx.call("pmd_tiles_project", ptr(src), ld_T, T, ptr(pix_loc_dev[b0:]), nb_, d, ptr(uw_dev[g0:]), dpad,
+                             ptr(proj), ld_T, 2)
+                    ctx.call("pmd_compact_rows", ptr(proj), ld_T, ptr(col_off_dev[g0:]), ptr(ranks_dev[g0:]), T, ptr(z), T, nb_)
+                    del proj
+            elif n_loc > 0:
+                if all_frames and ldv == ld_T:
+                    proj = v_dev     # same shape; the fit-frame traces are already compacted into v_cropped
+                else:
+                    proj = torch.empty((n_tiles, 64, ld_T), dtype=torch.float32, device=ctx.device)
+                ctx.call("pmd_tiles_project", ptr(src), ld_T, T, ptr(pix_loc_dev), n_loc, d, ptr(uw_dev[t_lo:]), dpad,
                          ptr(proj[t_lo:]), ld_T, 2)
                 ctx.call("pmd_compact_rows", ptr(proj[t_lo:]), ld_T, ptr(col_off_dev[t_lo:]), ptr(ranks_dev[t_lo:]), T, ptr(z), T,
                          n_loc)
+            if xs_full is None and K > 0:
+                # (UW)^T X = (UW)^T X_f + ((UW)^T B) (B^T X): bg_strip[k][c] = (B^T U W)[k][c], pj_dev = B^T X
+                lo_, hi_ = int(offsets[t_lo]), int(offsets[t_hi])
+                if hi_ > lo_:
+                    ctx.call("pmd_gemm", 1, 0, hi_ - lo_, T, K, 1.0, ptr(bg_strip[:, lo_:]), bg_strip.shape[1], ptr(pj_dev), ld_f, 1.0,
+                             ptr(z[lo_:]), T)
             if everywhere:
                 dist.gather_runs(z, [(int(offsets[lo]), int(offsets[hi])) for lo, hi in runs])
             if K > 0:
@@ -826,6 +900,7 @@ def localmd_decomposition(
             ctx.call("pmd_gram_blocks", ptr(uw_dev), dpad, b1, b2, ptr(pix_dev), ptr(pairs_dev), n_pairs, ptr(origins_dev),
                      ptr(col_off_dev), ptr(ranks_dev), n_tiles, Rt, ptr(basis_dev), D, max(K, 0), ptr(gblk), ptr(gbg),
                      ptr(gstrip), Rc)
+            bg_strip = gstrip
             nbr_ptr, nbr = grid.neighbour_lists(pairs, ranks, offsets[:-1], n_tiles, Rt, max(K, 0))
             nbr_ptr_dev, nbr_dev = _i32(ctx, nbr_ptr), _i32(ctx, nbr)
             ld_right = m_cols
@@ -957,6 +1032,8 @@ def localmd_decomposition(
             ctx.call("pmd_gram_u", ptr(uw_dev), dpad, b1, b2, ptr(pix_dev), ptr(pairs_dev), pairs.shape[0], ptr(origins_dev),
                      ptr(col_off_dev), ptr(ranks_dev), n_tiles, Rt, ptr(basis_dev), D, max(K, 0), ptr(G), Rc)
             _dbg("G", G)
+            if K > 0 and xs_full is None:
+                bg_strip = G[Rt:Rt + K, :].clone()   # G is overwritten by the eigendecomposition
             P_dev, rp = _orthogonalize(ctx, G, Rc, None, m_cols, m_cols)
             del G
         display("After performing rank reduction, the updated rank is {}".format(rp + (1 if null_tail else 0)))

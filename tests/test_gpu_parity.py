@@ -728,3 +728,34 @@ def test_full_pipeline_against_single_precision_lapack_oracle(gpu_ctx, case, mon
     mov = _movie(case["T"], case["d1"], case["d2"], seed=case["T"] // 3)
     pmd, diag, ref = _compare_full(gpu_ctx, mov, case["block"], case["frames"], sim_iters=8, **case["kw"])
     _check_full(pmd, diag, ref, mov, vt_tol=3e-3)
+
+
+def test_tile_batches_and_single_copy_plan_match_the_default_path(gpu_ctx):
+    """The memory plan for movies that fill the HBM (BASELINE configs 4 / 5): tiles fitted and projected in batches
+    (`tile_batch_bytes`), one standardised copy with the rank-K correction of the projection (`single_copy`).  Batching
+    must not change a bit of the tile results; the single-copy projection agrees to fp32 rounding.  Both routes of the
+    global stage (R <= frames, R > frames)."""
+    import localmd_amd
+    from localmd_amd import decomposition as Dm
+
+    Dm.QUIET = True
+    for mov, blk, kw in [(_movie(500, 60, 70, seed=4), (20, 20), dict(max_components=6, background_rank=3)),
+                         (_movie(300, 70, 80, seed=3), (10, 10), dict(max_components=8, background_rank=3))]:
+        outs = []
+        for extra in (dict(), dict(tile_batch_bytes=1), dict(tile_batch_bytes=1, single_copy=True), dict(single_copy=True)):
+            np.random.seed(7)
+            outs.append(localmd_amd.localmd_decomposition(mov, blk, mov.shape[0], seed=11, sim_iters=8, return_diagnostics=True,
+                                                          ctx=gpu_ctx, **kw, **extra))
+        (a, da), (b, db), (c, dc), (e, de) = outs
+        # batches of 64 tiles: same tile results bit for bit, same final result
+        np.testing.assert_array_equal(da["tile_ranks"], db["tile_ranks"])
+        np.testing.assert_array_equal(da["tile_ut"], db["tile_ut"])
+        np.testing.assert_array_equal(a.u.data, b.u.data)
+        np.testing.assert_allclose(b.s, a.s, rtol=1e-6)
+        for x in (c, e):
+            np.testing.assert_array_equal(x.u.indices, a.u.indices)
+            np.testing.assert_array_equal(x.u.data, a.u.data)
+            assert x.s.shape == a.s.shape
+            strong = a.s > 1e-2 * a.s[0]
+            np.testing.assert_allclose(x.s[strong], a.s[strong], rtol=2e-5)
+            assert PM.probes(x, a, mov.shape, n=400) < 2e-5
