@@ -680,6 +680,7 @@ def localmd_decomposition(
                 ctx.call("pmd_compact_rows", ptr(vb), ldv, ptr(off_b), ptr(rk), crop, ptr(piece), crop, nb_)
                 v_pieces.append(piece[:rows_b])
                 del vb
+            ctx.release_workspace()     # the batch workspace (GBs) is not needed again
         elif n_loc > 0:
             # several windows: first window = single_block_md, later ones fit the residual (decomposition.py:471-515);
             # the Gaussian matrix of (tile, window) is logical array tile * n_win + window
@@ -963,10 +964,14 @@ def localmd_decomposition(
                 if shard:
                     Et_dev.zero_()
                 nrow = row_hi - row_lo
+                Mt_buf = None
                 if nrow > 0:
-                    ws = ctx.workspace(lib.pmd_gram_mtgm_workspace_bytes(nrow, m_eff))
+                    # pmd_gram_mtgm writes the transposed copy of its M rows at the start of its workspace; handing it a
+                    # buffer of our own keeps that copy for the M^T Z product below (one transpose and, at BASELINE
+                    # config 5, 20 GB fewer than a second copy)
+                    Mt_buf = torch.empty((lib.pmd_gram_mtgm_workspace_bytes(nrow, m_eff) + 3) // 4, dtype=torch.float32, device=ctx.device)
                     ctx.call("pmd_gram_mtgm", ptr(right[row_lo:]), nrow, m_eff, ld_right, ptr(GM[row_lo:]), m_cols,
-                             ptr(Et_dev), m_cols, ptr(ws), ws.numel())
+                             ptr(Et_dev), m_cols, ptr(Mt_buf), Mt_buf.numel() * 4)
                 dist.all_reduce(Et_dev)
                 # The Cholesky step (C -> Et) is a chain of small latency-bound launches; the V projection
                 # Z = (UW)^T Y and the large product M^T Z do not depend on it.  Those are enqueued on the main
@@ -979,8 +984,7 @@ def localmd_decomposition(
                 Z = build_z(everywhere=not shard)
                 W1 = torch.zeros((m_eff, T), dtype=torch.float32, device=ctx.device)
                 if nrow > 0:
-                    Mt = torch.empty((m_eff, nrow), dtype=torch.float32, device=ctx.device)
-                    ctx.call("pmd_transpose", ptr(right[row_lo:]), m_cols, nrow, m_eff, ptr(Mt), nrow)
+                    Mt = Mt_buf[:m_eff * nrow].view(m_eff, nrow)
                     ctx.call("pmd_gemm", 0, 0, m_eff, T, nrow, 1.0, ptr(Mt), nrow, ptr(Z[row_lo:]), T, 0.0, ptr(W1), T)
                 lap("v_projection", t0)
                 t0 = time.perf_counter()
@@ -993,7 +997,7 @@ def localmd_decomposition(
                     ev_e.record(sc.stream)
                 main.wait_event(ev_e)
                 ctx.sync()
-                Mt = None
+                Mt = Mt_buf = None
                 chol_ok = bool(ok_c.value)
                 if chol_ok:
                     dist.all_reduce(W1)
