@@ -655,9 +655,11 @@ def localmd_decomposition(
         v_dev = None if batched else torch.empty((n_tiles, 64, ldv), dtype=torch.float32, device=ctx.device)
         v_pieces = []
 
-        def tiles_args(g0, nb_, v_out):
-            # g0: global index of the batch's first tile (the Gaussian matrix of a tile is keyed by it)
-            return (ptr(xf), ld_f, Dl, crop, ptr(pix_loc_dev[g0 - t_lo:]), nb_, b1, b2, ptr(pool_q_dev), pool_q.shape[1], P_pool,
+        def tiles_args(g0, nb_, v_out, x_rows=None, n_rows=None, pix_rows=None):
+            # g0: global index of the batch's first tile (the Gaussian matrix of a tile is keyed by it); a batch may hand over
+            # only the band of pixel rows its tiles touch (x_rows, n_rows) with pixel lists relative to it (pix_rows)
+            return (ptr(xf if x_rows is None else x_rows), ld_f, Dl if n_rows is None else n_rows, crop,
+                    ptr(pix_loc_dev[g0 - t_lo:] if pix_rows is None else pix_rows), nb_, b1, b2, ptr(pool_q_dev), pool_q.shape[1], P_pool,
                     ptr(pool_idx_dev), ptr(pool_w_dev), r, a_f, thr_s32, thr_t32, int(max_consecutive_failures), seed, g0, 1,
                     ptr(ut_dev[g0:]), ptr(v_out), ldv, ptr(stats_dev[g0:]), ptr(good_dev[g0:]), ptr(keep_dev[g0:]),
                     ptr(ranks_dev[g0:]), ptr(lam_dev[g0:]))
@@ -670,9 +672,14 @@ def localmd_decomposition(
             for b0, b1_ in batches:
                 nb_, g0 = b1_ - b0, t_lo + b0
                 vb = torch.empty((nb_, 64, ldv), dtype=torch.float32, device=ctx.device)
-                ws = ctx.workspace(lib.pmd_tiles_workspace_bytes(nb_, b1, b2, P_pool, r, a_f, crop, ldv, Dl))
-                _tiles_decompose(ctx, tiles_args(g0, nb_, vb), ws, (nb_, b1, b2, P_pool, r, a_f, crop, ldv, Dl, dpad),
-                                 temporal_denoiser, spatial_denoiser)
+                # the band of resident pixels the batch touches (tiles are in tile-row order): the temporal binning of the
+                # sketch walks only these rows instead of the whole movie once per batch (409 ms of 1.46 s at config 5)
+                lo_pix = int(pix_c[g0:g0 + nb_].min()) - P_lo
+                n_band = int(pix_c[g0:g0 + nb_].max()) + 1 - P_lo - lo_pix
+                pix_b = (pix_loc_dev[b0:b1_] - lo_pix).contiguous()
+                ws = ctx.workspace(lib.pmd_tiles_workspace_bytes(nb_, b1, b2, P_pool, r, a_f, crop, ldv, n_band))
+                _tiles_decompose(ctx, tiles_args(g0, nb_, vb, xf[lo_pix:], n_band, pix_b), ws,
+                                 (nb_, b1, b2, P_pool, r, a_f, crop, ldv, n_band, dpad), temporal_denoiser, spatial_denoiser)
                 rk = ranks_dev[g0:g0 + nb_]
                 off_b = (torch.cumsum(rk, 0) - rk).to(torch.int32)
                 rows_b = int(rk.sum().item())
