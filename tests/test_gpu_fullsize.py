@@ -26,7 +26,7 @@ def _decompose(gpu_ctx, T, d1, d2, block, max_components, seed=11):
     return pmd, diag, noisy
 
 
-def _check_properties(pmd, diag, noisy, T, d1, d2, block, clean_band=None):
+def _check_properties(pmd, diag, noisy, T, d1, d2, block, clean_band=None, noisy_is_band=False):
     """clean_band = (i_lo, i_hi): build the noiseless ground truth for these FOV rows only and probe inside them (the
     84 GB movies of BASELINE configs 4 / 5 leave no room for a second full movie)."""
     import torch
@@ -83,7 +83,7 @@ def _check_properties(pmd, diag, noisy, T, d1, d2, block, clean_band=None):
     for q, (a, b) in enumerate(zip(pi[:40], pj[:40])):
         trace = traces[:, q]
         c = clean[:, a - band[0], b].cpu().numpy()
-        y = noisy[:, a, b].cpu().numpy()
+        y = noisy[:, a - (band[0] if noisy_is_band else 0), b].cpu().numpy()
         err_rec.append(np.mean((trace - c) ** 2))
         err_in.append(np.mean((y - c) ** 2))
     assert np.mean(err_rec) < 0.6 * np.mean(err_in), (np.mean(err_rec), np.mean(err_in))
@@ -192,3 +192,40 @@ def test_config4_1024x1024x20000_one_gpu_properties(gpu_ctx):
     gpu_ctx.release_workspace()
     torch.cuda.empty_cache()
     _check_properties(pmd, diag, noisy, T, d1, d2, block, clean_band=(480, 544))
+
+
+@pytest.mark.slow
+@pytest.mark.skipif(__import__("os").environ.get("PMD_RUN_SLOW", "") != "1", reason="84 GB movie, ~1 minute: set PMD_RUN_SLOW=1")
+def test_config5_2048x2048x5000_one_gpu_properties(gpu_ctx):
+    """BASELINE config 5 at full size on ONE GPU: 65 025 tiles of 16 x 16 pixels, > 10^6 tile components.  The movie is handed
+    over through a one-shot source so that the decomposition can release the raw copy (peak 202 GB measured); tiles run in
+    batches."""
+    import torch
+    import localmd_amd
+    from localmd_amd import decomposition as Dm
+    from localmd_amd.synthetic import make_movie_torch
+
+    free, total = torch.cuda.mem_get_info()
+    if total < 250 * 2 ** 30:
+        pytest.skip("needs 288 GB of HBM")
+    Dm.QUIET = True
+    T, d1, d2, block = 5000, 2048, 2048, 16
+
+    class OneShot:
+        def __init__(self, t):
+            self.shape, self._t = tuple(t.shape), t
+
+        def slab(self, i_lo, i_hi):
+            t, self._t = self._t, None
+            return t[:, i_lo:i_hi, :]
+
+    src = OneShot(make_movie_torch(T, d1, d2, gpu_ctx.device, seed=0, noise=1.0))
+    np.random.seed(0)
+    pmd, diag = localmd_amd.localmd_decomposition(src, (block, block), T, max_components=50, seed=11, ctx=gpu_ctx,
+                                                  return_diagnostics=True, sim_iters=50)
+    assert len(diag["tile_ranks"]) == 65025 and pmd.s.shape == (T,)
+    gpu_ctx.release_workspace()
+    torch.cuda.empty_cache()
+    band = (1000, 1064)
+    noisy_band = make_movie_torch(T, d1, d2, gpu_ctx.device, seed=0, noise=1.0, rows=band)
+    _check_properties(pmd, diag, noisy_band, T, d1, d2, block, clean_band=band, noisy_is_band=True)
