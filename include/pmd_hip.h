@@ -145,6 +145,17 @@ int pmd_compact_rows(pmd_ctx* ctx, const float* Out, long ldo, const int* col_of
 int pmd_gram_u(pmd_ctx* ctx, const float* Uw, int dpad, int b1, int b2, const int* tile_pix, const int* pairs,
                int n_pairs, const int* origins, const int* col_off, const int* ranks, int n_tiles, int Rt,
                const float* basis, long D, int K, float* G, long ldg);
+/* RCCL at this boundary, for a caller that is not built on torch.distributed: one communicator per context,
+ * collectives enqueued on the context's stream.  pmd_comm_unique_id: 128 bytes from rank 0, to be broadcast out of band
+ * (ncclGetUniqueId); pmd_comm_init: ncclCommInitRank on the context's device; the sharded path needs an in-place fp32
+ * sum (partial M^T G M / M^T Z / background projections) and an all-gather of equal-sized blocks
+ * (per-tile results).  RCCL is resolved with dlopen at the first call: no link-time dependency, and a process that
+ * already holds an RCCL (PyTorch's) shares it.  localmd_amd/parallel.py uses torch.distributed (backend "nccl" = RCCL). */
+int pmd_comm_unique_id(void* out128);
+int pmd_comm_init(pmd_ctx* ctx, const void* unique_id128, int rank, int world);
+int pmd_comm_destroy(pmd_ctx* ctx);
+int pmd_comm_all_reduce_f32(pmd_ctx* ctx, float* buf, size_t count);
+int pmd_comm_all_gather(pmd_ctx* ctx, const void* send, void* recv, size_t bytes_per_rank);
 /* Which eigen-directions pmd_orthogonalize / pmd_orthogonalize_factored keep.  rel_cutoff < 0 (default): the
  * reference's rule - jnp.linalg.svd(hermitian=True) returns |lambda| and u = v sign(lambda), so `eig_vals > 0`
  * (decomposition.py:988) keeps every direction whose eigenvalue is not exactly zero, numerically null ones included.

@@ -16,6 +16,7 @@ c_u64, c_u32, c_sz = C.c_uint64, C.c_uint32, C.c_size_t
 # name -> (restype, argtypes); every symbol declared in include/pmd_hip.h
 SIGNATURES = {
     "pmd_version": (c_i, []),
+    "pmd_comm_unique_id": (c_i, [c_p]),
     "pmd_ctx_create": (c_i, [c_i, c_p, C.POINTER(c_p)]),
     "pmd_ctx_destroy": (c_i, [c_p]),
     "pmd_ctx_set_stream": (c_i, [c_p, c_p]),
@@ -77,6 +78,10 @@ SIGNATURES = {
     "pmd_chol_inverse_workspace_bytes": (c_sz, [c_i]),
     "pmd_chol_inverse": (c_i, [c_p, c_p, c_i, c_l, c_i, C.POINTER(c_i), c_p, c_sz]),
     "pmd_ctx_set_null_cutoff": (c_i, [c_p, C.c_float]),
+    "pmd_comm_init": (c_i, [c_p, c_p, c_i, c_i]),
+    "pmd_comm_destroy": (c_i, [c_p]),
+    "pmd_comm_all_reduce_f32": (c_i, [c_p, c_p, c_sz]),
+    "pmd_comm_all_gather": (c_i, [c_p, c_p, c_p, c_sz]),
     "pmd_transpose": (c_i, [c_p, c_p, c_l, c_i, c_i, c_p, c_l]),
     "pmd_csr_count": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_p]),
     "pmd_csr_fill": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_i,

@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")"
 OUT=../libpmd_hip.so
-SRCS="capi.hip rng.hip prep.hip tile_gemm.hip small_la.hip pipeline.hip global.hip sytrd.hip expand.hip diag.hip"
+SRCS="capi.hip rng.hip prep.hip tile_gemm.hip small_la.hip pipeline.hip global.hip sytrd.hip expand.hip diag.hip comm.hip"
 OBJS=""
 mkdir -p build
 for s in $SRCS; do
@@ -14,5 +14,5 @@ for s in $SRCS; do
   OBJS="$OBJS $o"
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o $OUT -L/opt/rocm/lib -lrocblas -lrocsolver -Wl,-rpath,/opt/rocm/lib
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o $OUT -L/opt/rocm/lib -lrocblas -lrocsolver -ldl -Wl,-rpath,/opt/rocm/lib
 echo "built $(realpath $OUT)"

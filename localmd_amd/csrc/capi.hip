@@ -35,6 +35,9 @@ int pmd_ctx_create(int device, void* hip_stream, pmd_ctx** out) {
   ctx->err[0] = 0;
   ctx->profile = false;
   ctx->null_cutoff = -1.f;
+  ctx->comm = nullptr;
+  ctx->comm_rank = 0;
+  ctx->comm_world = 0;
   ctx->atx_label = nullptr;
   if (rocblas_create_handle(&ctx->blas) != rocblas_status_success) { delete ctx; return PMD_ERR_BLAS; }
   rocblas_set_stream(ctx->blas, ctx->stream);
@@ -47,12 +50,33 @@ int pmd_ctx_create(int device, void* hip_stream, pmd_ctx** out) {
 int pmd_ctx_destroy(pmd_ctx* ctx) {
   CTX_CHECK(ctx);
   hipSetDevice(ctx->device);
+  if (ctx->comm) pmd_comm_destroy_impl(ctx);
   if (ctx->tables) hipFree(ctx->tables);
   if (ctx->scratch) hipFree(ctx->scratch);
   if (ctx->split_ws) hipFree(ctx->split_ws);
   if (ctx->blas) rocblas_destroy_handle(ctx->blas);
   delete ctx;
   return PMD_OK;
+}
+
+int pmd_comm_unique_id(void* out128) { return pmd_comm_unique_id_impl(out128); }
+int pmd_comm_init(pmd_ctx* ctx, const void* unique_id128, int rank, int world) {
+  CTX_CHECK(ctx);
+  return pmd_comm_init_impl(ctx, unique_id128, rank, world);
+}
+int pmd_comm_destroy(pmd_ctx* ctx) {
+  CTX_CHECK(ctx);
+  return pmd_comm_destroy_impl(ctx);
+}
+int pmd_comm_all_reduce_f32(pmd_ctx* ctx, float* buf, size_t count) {
+  CTX_CHECK(ctx);
+  if (!buf && count) return pmd_fail(ctx, PMD_ERR_ARG, "pmd_comm_all_reduce_f32", "null pointer");
+  return pmd_comm_all_reduce_f32_impl(ctx, buf, count);
+}
+int pmd_comm_all_gather(pmd_ctx* ctx, const void* send, void* recv, size_t bytes_per_rank) {
+  CTX_CHECK(ctx);
+  if ((!send || !recv) && bytes_per_rank) return pmd_fail(ctx, PMD_ERR_ARG, "pmd_comm_all_gather", "null pointer");
+  return pmd_comm_all_gather_impl(ctx, send, recv, bytes_per_rank);
 }
 
 int pmd_ctx_set_null_cutoff(pmd_ctx* ctx, float rel_cutoff) {

@@ -42,6 +42,8 @@ struct pmd_ctx {
   double gemm_split_min_flop;        // ... for products with at least this many flops
   void* split_ws;                    // library-owned device scratch of the split products (bf16 pieces)
   size_t split_ws_bytes;
+  void* comm;                        // RCCL communicator (pmd_comm_init), NULL without one
+  int comm_rank, comm_world;
   float null_cutoff;                 // < 0: keep every direction with lambda != 0, scaled by 1/sqrt(|lambda|) (decomposition.py:984-996);
                                      // >= 0: keep lambda > null_cutoff * lambda_max only (pmd_ctx_set_null_cutoff)
   bool profile;                      // pmd_profile_enable: HIP events around every kernel group

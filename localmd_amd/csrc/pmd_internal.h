@@ -58,6 +58,11 @@ int pmd_launch_decide(pmd_ctx* ctx, const float* stats, int r, float thr_s, floa
 // expand.hip
 int pmd_csr_rows_spmm_impl(pmd_ctx* ctx, const long* indptr, const int* indices, const float* data, const int* rows,
                            long n_sel, const float* B, long ldb, int ncols, float* out, long ldo);
+int pmd_comm_unique_id_impl(void* out128);
+int pmd_comm_init_impl(pmd_ctx* ctx, const void* unique_id128, int rank, int world);
+int pmd_comm_destroy_impl(pmd_ctx* ctx);
+int pmd_comm_all_reduce_f32_impl(pmd_ctx* ctx, float* buf, size_t count);
+int pmd_comm_all_gather_impl(pmd_ctx* ctx, const void* send, void* recv, size_t bytes_per_rank);
 size_t pmd_diag_workspace_bytes_impl(long T, long D);
 int pmd_neighbour_moments_impl(pmd_ctx* ctx, const float* A, const float* B, const float* ref, long T, int d1, int d2,
                                int accumulate, double* moments, void* ws, size_t ws_bytes);

@@ -569,3 +569,29 @@ def test_gemm_long_inner_dimension_split(gpu_ctx, ta, tb):
     err = (C[:, :n].double() - ref).abs().max().item() / ref.abs().max().item()
     assert err < 2e-6, err
     assert torch.equal(C[:, n:], C0[:, n:])
+
+
+def test_comm_entry_points_single_rank(gpu_ctx):
+    """pmd_comm_* (RCCL at the C ABI): a one-rank communicator on the test box's only GPU - unique id,
+    init, in-place all-reduce and all-gather on the context's stream, destroy.  (More ranks need one GPU each; the
+    multi-rank data path of the package runs over torch.distributed, tests/test_gpu_distributed.py.)"""
+    import ctypes as C
+
+    torch = _t()
+    ctx = gpu_ctx
+    uid = C.create_string_buffer(128)
+    assert ctx.lib.pmd_comm_unique_id(uid) == 0
+    ctx.call("pmd_comm_init", uid, 0, 1)
+    try:
+        x = torch.arange(1000, dtype=torch.float32, device=ctx.device)
+        ctx.call("pmd_comm_all_reduce_f32", P(x), x.numel())
+        y = torch.empty(4096, dtype=torch.uint8, device=ctx.device)
+        src = torch.arange(4096, device=ctx.device).to(torch.uint8)
+        ctx.call("pmd_comm_all_gather", P(src), P(y), 4096)
+        ctx.sync()
+        assert torch.equal(x, torch.arange(1000, dtype=torch.float32, device=ctx.device))
+        assert torch.equal(y, src)
+        with pytest.raises(Exception):
+            ctx.call("pmd_comm_init", uid, 0, 1)     # one communicator per context
+    finally:
+        ctx.call("pmd_comm_destroy")
