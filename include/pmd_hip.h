@@ -278,6 +278,11 @@ int pmdk_syevd(pmd_ctx* ctx, int n, float* A, long lda, float* w, float* work, i
  * of the buffer (memory row c holds A(r, c), r >= c, at offset r): d[n], e[n-1], tau[n-1], reflectors in A.
  * impl 0 = rocSOLVER, 1 = the library's own kernels (lda % 4 == 0, lda >= round_up(n, 4)). */
 int pmdk_sytrd(pmd_ctx* ctx, int n, float* A, long lda, float* d, float* e, float* tau, int impl);
+/* stage 1 of the two-stage reduction (sytrd2.hip): dense -> band of half bandwidth 64; reflectors of Q1 below the band
+ * (unit entry of reflector c at position c + 64), tau1[n]; *flag_host != 0: a panel was rank deficient */
+int pmdk_sy2sb(pmd_ctx* ctx, int n, float* A, long lda, float* tau1, int* flag_host);
+/* stages 1 + 2: dense -> band -> tridiagonal (bulge chasing); d[n], e[n - 1] on the device */
+int pmdk_sytrd2(pmd_ctx* ctx, int n, float* A, long lda, float* tau1, float* d, float* e, int* flag_host);
 
 #ifdef __cplusplus
 }

@@ -97,6 +97,8 @@ SIGNATURES = {
     "pmdk_roughness": (c_i, [c_p, c_p, c_l, c_i, c_i, c_i, c_p, c_l, c_l, c_i, c_i, c_p, c_i]),
     "pmdk_syevd": (c_i, [c_p, c_i, c_p, c_l, c_p, c_p, c_p]),
     "pmdk_sytrd": (c_i, [c_p, c_i, c_p, c_l, c_p, c_p, c_p, c_i]),
+    "pmdk_sy2sb": (c_i, [c_p, c_i, c_p, c_l, c_p, C.POINTER(c_i)]),
+    "pmdk_sytrd2": (c_i, [c_p, c_i, c_p, c_l, c_p, c_p, c_p, C.POINTER(c_i)]),
 }
 
 _lib = None

@@ -447,6 +447,33 @@ int pmdk_syevd(pmd_ctx* ctx, int n, float* A, long lda, float* w, float* work, i
   return pmd_syevd(ctx, n, A, lda, w, work, info);
 }
 
+// stage 1 of the two-stage reduction alone (tests): dense -> band; the workspace is allocated and freed inside
+int pmdk_sy2sb(pmd_ctx* ctx, int n, float* A, long lda, float* tau1, int* flag_host) {
+  CTX_CHECK(ctx);
+  const size_t bytes = pmd_sy2sb_workspace_bytes_impl(n);
+  void* ws = nullptr;
+  if (hipMalloc(&ws, bytes) != hipSuccess) return pmd_fail(ctx, PMD_ERR_HIP, "pmdk_sy2sb", "hipMalloc");
+  const int rc = pmd_sy2sb_impl(ctx, n, A, lda, tau1, flag_host, ws, bytes);
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipFree(ws);
+  return rc;
+}
+
+// stages 1 + 2 (tests): dense -> band -> tridiagonal; d[n], e[n - 1] on the device
+int pmdk_sytrd2(pmd_ctx* ctx, int n, float* A, long lda, float* tau1, float* d, float* e, int* flag_host) {
+  CTX_CHECK(ctx);
+  const size_t b1 = pmd_sy2sb_workspace_bytes_impl(n), b2 = pmd_sb2st_workspace_bytes_impl(n);
+  void *w1 = nullptr, *w2 = nullptr;
+  if (hipMalloc(&w1, b1) != hipSuccess || hipMalloc(&w2, b2) != hipSuccess) return pmd_fail(ctx, PMD_ERR_HIP, "pmdk_sytrd2", "hipMalloc");
+  int rc = pmd_sy2sb_impl(ctx, n, A, lda, tau1, flag_host, w1, b1);
+  float *V2 = nullptr, *tau2 = nullptr;
+  if (rc == PMD_OK) rc = pmd_sb2st_impl(ctx, n, A, lda, d, e, &V2, &tau2, w2, b2);
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipFree(w1);
+  (void)hipFree(w2);
+  return rc;
+}
+
 int pmdk_sytrd(pmd_ctx* ctx, int n, float* A, long lda, float* d, float* e, float* tau, int impl) {
   CTX_CHECK(ctx);
   return pmd_sytrd_auto(ctx, n, A, lda, d, e, tau, impl);

@@ -95,6 +95,15 @@ int pmd_background_rsvd_impl(pmd_ctx* ctx, const float* xs, long D, int n, long 
 int pmd_gemm_rm(pmd_ctx* ctx, int transA, int transB, int m, int n, int k, float alpha, const float* A, long lda,
                 const float* B, long ldb, float beta, float* C, long ldc);
 int pmd_syevd(pmd_ctx* ctx, int n, float* A, long lda, float* w, float* work, int* info);
+size_t pmd_sy2sb_workspace_bytes_impl(int n);
+int pmd_sy2sb_impl(pmd_ctx* ctx, int n, float* A, long lda, float* tau1, int* flag_host, void* ws, size_t ws_bytes);
+int pmd_apply_q_off_impl(pmd_ctx* ctx, int n, const float* A, long lda, const float* tau, float* Z, long ldz, void* ws,
+                         size_t ws_bytes, int off);
+int pmd_syevd_two_stage(pmd_ctx* ctx, int n, float* A, long lda, float* w, int* info, int* done);
+int pmd_sb2st_apply_q2_impl(pmd_ctx* ctx, int n, const float* V2, const float* tau2, float* Z, long ldz, int nvec);
+size_t pmd_sb2st_workspace_bytes_impl(int n);
+int pmd_sb2st_impl(pmd_ctx* ctx, int n, const float* A, long lda, float* d, float* e, float** V2_out, float** tau2_out,
+                   void* ws, size_t ws_bytes);
 int pmd_sytrd_auto(pmd_ctx* ctx, int n, float* A, long lda, float* d, float* e, float* tau, int impl);
 int pmd_launch_weight_tiles(pmd_ctx* ctx, const float* Ut, int dpad, const int* pix, int d, const float* w,
                             const float* cumw, const int* ranks, float* Uw, int n_tiles);

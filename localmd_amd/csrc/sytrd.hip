@@ -754,9 +754,9 @@ __global__ void copy_rows_kernel(const float* __restrict__ src, long lds_, float
 // Vb[k][r - p0] = reflector k0 + k at position r (0 before its unit entry, 1 at k0 + k + 1); a reflector
 // with tau = 0 is the identity and becomes a zero row
 __global__ void extract_v_kernel(const float* __restrict__ A, long lda, const float* __restrict__ tau, int k0, int p0,
-                                 int np, float* __restrict__ Vb, long ldv) {
+                                 int np, float* __restrict__ Vb, long ldv, int off) {
   const int k = blockIdx.y;
-  const int unit = k0 + k + 1;
+  const int unit = k0 + k + off;       // off = 1: tridiagonalisation of this file; off = 64: band reduction of sytrd2.hip
   const bool dead = tau[k0 + k] == 0.f;
   for (int rr = blockIdx.x * blockDim.x + threadIdx.x; rr < np; rr += gridDim.x * blockDim.x) {
     const int r = p0 + rr;
@@ -794,19 +794,25 @@ size_t pmd_apply_q_workspace_bytes_impl(int n) {
 
 int pmd_apply_q_impl(pmd_ctx* ctx, int n, const float* A, long lda, const float* tau, float* Z, long ldz, void* ws,
                      size_t ws_bytes) {
+  return pmd_apply_q_off_impl(ctx, n, A, lda, tau, Z, ldz, ws, ws_bytes, 1);
+}
+
+// off: distance of a reflector's unit entry below the diagonal (reflector c = [1 at position c + off, A[c][c + off + 1 ..)])
+int pmd_apply_q_off_impl(pmd_ctx* ctx, int n, const float* A, long lda, const float* tau, float* Z, long ldz, void* ws,
+                         size_t ws_bytes, int off) {
   pmd_prof_scope prof__(ctx, "apply_q");
-  if (n < 2) return PMD_OK;
+  if (n < off + 1) return PMD_OK;
   pmd_arena ar(ws, ws_bytes);
   float* Vb = ar.take_n<float>((size_t)QB * n);
   float* S = ar.take_n<float>((size_t)QB * QB);
   float* Y = ar.take_n<float>((size_t)n * QB);
   if (ar.overflow) return pmd_fail(ctx, PMD_ERR_WORKSPACE, "pmd_apply_q", "workspace too small");
-  const int nref = n - 1;
+  const int nref = n - off;
   const float one = 1.f;
   for (int k0 = (nref - 1) / QB * QB; k0 >= 0; k0 -= QB) {
     const int kb = std::min(QB, nref - k0);
-    const int p0 = k0 + 1, np = n - p0;
-    hipLaunchKernelGGL(extract_v_kernel, dim3((np + 255) / 256, kb), dim3(256), 0, ctx->stream, A, lda, tau, k0, p0, np, Vb, (long)np);
+    const int p0 = k0 + off, np = n - p0;
+    hipLaunchKernelGGL(extract_v_kernel, dim3((np + 255) / 256, kb), dim3(256), 0, ctx->stream, A, lda, tau, k0, p0, np, Vb, (long)np, off);
     PMD_LAUNCH_CHECK(ctx, "extract_v_kernel");
     int rc = pmd_gemm_rm(ctx, 0, 1, kb, kb, np, 1.f, Vb, np, Vb, np, 0.f, S, kb);
     if (rc != PMD_OK) return rc;
@@ -960,6 +966,47 @@ int pmd_sytrd_auto(pmd_ctx* ctx, int n, float* A, long lda, float* d, float* e, 
   return pmd_sytrd_impl(ctx, n, A, lda, d, e, tau, scratch, tb);
 }
 
+// Two-stage path (sytrd2.hip): A = Q1 B Q1^T (band), B = Q2 T Q2^T (tridiagonal), sstedc, E = Q1 (Q2 Z).  *done = 0 and A
+// untouched when a panel of stage 1 was numerically rank deficient.
+int pmd_syevd_two_stage(pmd_ctx* ctx, int n, float* A, long lda, float* w, int* info, int* done) {
+  *done = 0;
+  const size_t b1 = pmd_sy2sb_workspace_bytes_impl(n), b2 = pmd_sb2st_workspace_bytes_impl(n);
+  const size_t bq = pmd_apply_q_workspace_bytes_impl(n);
+  const size_t zb = (size_t)n * n * sizeof(float), ab = (size_t)n * lda * sizeof(float);
+  void* scratch = nullptr;
+  int rc = ctx_scratch(ctx, zb + ab + std::max(b1, bq) + b2 + 4 * (size_t)n * sizeof(float) + 16384, &scratch);
+  if (rc != PMD_OK) return rc;
+  pmd_arena ar(scratch, ctx->scratch_bytes);
+  float* Z = ar.take_n<float>((size_t)n * n);
+  float* W = ar.take_n<float>((size_t)n * lda);     // working copy: stage 1 overwrites it with the band and the reflectors
+  float* e = ar.take_n<float>(n);
+  float* tau1 = ar.take_n<float>(n);
+  void* w1 = ar.take(std::max(b1, bq));
+  void* w2 = ar.take(b2);
+  if (ar.overflow) return pmd_fail(ctx, PMD_ERR_WORKSPACE, "pmd_syevd_two_stage", "scratch too small");
+  PMD_HIP(ctx, hipMemcpyAsync(W, A, ab, hipMemcpyDeviceToDevice, ctx->stream));
+  int flag = 0;
+  rc = pmd_sy2sb_impl(ctx, n, W, lda, tau1, &flag, w1, b1);
+  if (rc != PMD_OK) return rc;
+  if (flag) return PMD_OK;
+  float *V2 = nullptr, *tau2 = nullptr;
+  rc = pmd_sb2st_impl(ctx, n, W, lda, w, e, &V2, &tau2, w2, b2);
+  if (rc != PMD_OK) return rc;
+  {
+    pmd_prof_scope prof__(ctx, "rocsolver_sstedc");
+    rocblas_status st = rocsolver_sstedc(ctx->blas, rocblas_evect_tridiagonal, n, w, e, Z, n, info);
+    if (st != rocblas_status_success) return pmd_fail(ctx, PMD_ERR_BLAS, "rocsolver_sstedc", rocblas_status_to_string(st));
+  }
+  rc = pmd_sb2st_apply_q2_impl(ctx, n, V2, tau2, Z, n, n);
+  if (rc != PMD_OK) return rc;
+  rc = pmd_apply_q_off_impl(ctx, n, W, lda, tau1, Z, n, w1, bq, 64);
+  if (rc != PMD_OK) return rc;
+  hipLaunchKernelGGL(copy_rows_kernel, dim3(8, n), dim3(256), 0, ctx->stream, Z, (long)n, A, lda, n);
+  PMD_LAUNCH_CHECK(ctx, "copy_rows_kernel");
+  *done = 1;
+  return PMD_OK;
+}
+
 // Symmetric eigendecomposition, ascending eigenvalues; on exit memory row j of A is eigenvector j.
 // Only the row-major upper triangle of A (= column-major lower) is read.  work: n floats, info: device int.
 int pmd_syevd(pmd_ctx* ctx, int n, float* A, long lda, float* w, float* work, int* info) {
@@ -971,6 +1018,13 @@ int pmd_syevd(pmd_ctx* ctx, int n, float* A, long lda, float* w, float* work, in
     pmd_prof_scope prof__(ctx, "rocsolver_ssyevd");
     PMD_BLAS(ctx, rocsolver_ssyevd(ctx->blas, rocblas_evect_original, rocblas_fill_lower, n, A, (rocblas_int)lda, w, work, info));
     return PMD_OK;
+  }
+  const bool two_stage = mode && !strcmp(mode, "twostage") && n >= 256;
+  if (two_stage) {
+    int done = 0;
+    const int rc2 = pmd_syevd_two_stage(ctx, n, A, lda, w, info, &done);
+    if (rc2 != PMD_OK) return rc2;
+    if (done) return PMD_OK;     // else: a rank-deficient panel; A is untouched, the one-stage path below takes over
   }
   const size_t tb = std::max(pmd_sytrd_workspace_bytes_impl(n), pmd_apply_q_workspace_bytes_impl(n));
   const size_t zb = (size_t)n * n * sizeof(float);
