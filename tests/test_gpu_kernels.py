@@ -414,6 +414,47 @@ def test_syevd_own_path(gpu_ctx, n, force, monkeypatch):
     assert np.abs(E @ S64 - wv[:, None] * E).max() < 1e-5 * np.abs(S64).max() * np.sqrt(n)
 
 
+@pytest.mark.parametrize("n,rank", [(300, None), (1030, None), (2117, None), (600, 100)])
+def test_syevd_two_stage_route(gpu_ctx, n, rank, monkeypatch):
+    """PMD_SYEVD=twostage: dense -> band -> tridiagonal (sytrd2.hip), sstedc, both back-transformations.  An exactly zero
+    trailing block (rank given: only the leading rank x rank block is set) makes a panel of stage 1 singular: the call has to
+    fall back to the one-stage route, same contract."""
+    torch = _t()
+    ctx = gpu_ctx
+    monkeypatch.setenv("PMD_SYEVD", "twostage")
+    rng = np.random.default_rng(n)
+    if rank is None:
+        S = _sym_matrix(rng, n)
+    else:
+        S = np.zeros((n, n), dtype=np.float32)
+        S[:rank, :rank] = _sym_matrix(rng, rank)
+    ld = (n + 3) // 4 * 4
+    buf = np.zeros((n, ld), dtype=np.float32)
+    buf[:, :n] = S
+    Sd = dev(ctx, buf)
+    w = torch.empty(n, dtype=torch.float32, device=ctx.device)
+    work = torch.empty(n, dtype=torch.float32, device=ctx.device)
+    info = torch.zeros(4, dtype=torch.int32, device=ctx.device)
+    ctx.profile_enable(True)
+    ctx.call("pmdk_syevd", n, P(Sd), ld, P(w), P(work), P(info))
+    ctx.sync()
+    prof = ctx.profile_summary()
+    ctx.profile_enable(False)
+    assert "sy2sb" in prof, prof
+    if rank is None:
+        assert "sb2st" in prof and "apply_q2" in prof and "sytrd" not in prof, prof
+    else:
+        assert "sytrd" in prof, prof  # the fallback ran
+    assert int(info[0]) == 0
+    wv = w.cpu().numpy().astype(np.float64)
+    E = Sd.cpu().numpy()[:, :n].astype(np.float64)
+    S64 = S.astype(np.float64)
+    assert np.all(np.diff(wv) >= 0)
+    np.testing.assert_allclose(wv, np.linalg.eigvalsh(S64), atol=3e-6 * np.abs(S64).max() * np.sqrt(n))
+    assert np.abs(E @ E.T - np.eye(n)).max() < 5e-5 * np.sqrt(n)
+    assert np.abs(E @ S64 - wv[:, None] * E).max() < 1e-5 * np.abs(S64).max() * np.sqrt(n)
+
+
 @pytest.mark.parametrize("m", [90, 300, 515])
 def test_orthogonalize_chol_blocked(gpu_ctx, m):
     """Et = U_c^{-T} with M^T (G M) = U_c^T U_c: lower triangular, Et C Et^T = I (several 128-blocks)."""
