@@ -943,6 +943,7 @@ def localmd_decomposition(
                     GM[Rt:Rt + K, :ncols] = part
 
             chol_ok = False
+            hv_dev = None
             if orthogonalizer in ("auto", "cholesky"):
                 m_eff = m_cols
                 abs_last = 0
@@ -1026,6 +1027,14 @@ def localmd_decomposition(
                 elif orthogonalizer == "cholesky":
                     raise PMDLibraryError("orthogonalizer='cholesky': U^T U restricted to the right matrix is not positive definite")
             if not chol_ok:
+                if hv_dev is not None:
+                    # Undo the rotation (H is an involution).  With the null direction isolated in the last column, the
+                    # eigensolver returns an eigenvalue for it that is orders of magnitude below the rounding level of
+                    # the unrotated matrix, and the reference's 1 / sqrt(|lambda|) rule then scales that direction up
+                    # until it swamps every other component (seen in the seeded fuzz: mean squared residual 1400
+                    # instead of 1.3).  Unrotated, the route is exactly the eigenvector route the caller can also ask for.
+                    ctx.call("pmd_gemm", 0, 0, Rc, 1, m_cols, 1.0, ptr(right), ld_right, ptr(hv_dev), 1, 0.0, ptr(y_dev), 1)
+                    ctx.call("pmd_gemm", 0, 0, Rc, m_cols, 1, -2.0, ptr(y_dev), 1, ptr(hv_dev), m_cols, 1.0, ptr(right), ld_right)
                 if shard:
                     dist.gather_runs(right, row_bounds)   # only the halo rows were exchanged so far
                 shard = False  # eigenvector route: replicated on every rank

@@ -49,15 +49,48 @@ def draw_cases(n_cases, seed=FUZZ_SEED):
     return out
 
 
+def draw_wide_cases(n_cases, seed):
+    """Draws aimed at the R > frames routes of the global stage: many small tiles, few frames."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for case in range(n_cases):
+        b1, b2 = (int(2 * rng.integers(5, 9)) for _ in range(2))
+        d1 = int(rng.integers(4 * b1, 7 * b1))
+        d2 = int(rng.integers(4 * b2, 7 * b2))
+        taf = int(rng.choice([1, 2, 4, 5]))
+        T = int(rng.integers(260, 520))
+        frames = T if rng.random() < 0.6 else int(rng.integers(256, T))
+        kw = dict(max_components=int(rng.integers(4, 13)), background_rank=int(rng.integers(0, 4)), temporal_avg_factor=taf,
+                  spatial_avg_factor=int(rng.choice([1, 2])), order=str(rng.choice(["F", "C"])),
+                  compute_normalizer=bool(rng.random() < 0.8), max_consecutive_failures=int(rng.choice([1, 1, 2])))
+        out.append((case, T, d1, d2, b1, b2, frames, kw))
+    return out
+
+
 def passing_span_singular_values(res, passed, n_tile_cols, mov, mean_img, std_img, order):
     """Singular values (float64) of the standardised movie projected on span(U[:, passing tile columns + background])."""
     T = mov.shape[0]
     u = res.u.tocsc()
     keep = np.ones(u.shape[1], bool)
     keep[:n_tile_cols] = passed
+    # An all-zero column (the reference's placeholder for background_rank = 0) must not enter the QR: its Householder
+    # step is the identity and its column of Q a vector of the orthogonal complement that depends on the signs of
+    # rounding-level pivots - on sparse columns those differ between two runs that agree to 1e-7.
+    keep &= np.asarray(np.abs(u).sum(axis=0)).reshape(-1) > 0
     q, _ = np.linalg.qr(np.asarray(u[:, keep].todense(), dtype=np.float64))
     y = ((mov.astype(np.float64) - mean_img[None]) / std_img[None]).reshape(T, -1, order=order).T
     return np.linalg.svd(q.T @ y, compute_uv=False), int(keep.sum())
+
+
+def probe_fit(res, mov, mean_img, std_img, order, n_probes=600):
+    """Mean squared residual of the reconstruction against the standardised data on fixed random probes."""
+    T, d1, d2 = mov.shape
+    rng_ = np.random.default_rng(0)
+    pi, pt = rng_.integers(0, d1 * d2, n_probes), rng_.integers(0, T, n_probes)
+    y = ((mov - mean_img[None]) / std_img[None]).reshape(T, -1, order=order)[pt, pi]
+    rec = np.einsum("pk,k,kp->p", np.asarray(res.u.tocsr()[pi] @ res.r, dtype=np.float64), np.asarray(res.s, dtype=np.float64),
+                    np.asarray(res.v[:, pt], dtype=np.float64))
+    return float(np.mean((rec - y) ** 2))
 
 
 def run_case(ctx, case, T, d1, d2, b1, b2, frames, kw, out=None):
@@ -113,13 +146,11 @@ def run_case(ctx, case, T, d1, d2, b1, b2, frames, kw, out=None):
         for t in np.nonzero(dr)[0][:6]:
             say(f"   tile {t}: ranks {diag['tile_ranks'][t]} vs {ref.diag['tile_ranks'][t]}, knife-edge: {bool(knife[t])}")
     # fit to the data on random probes (the quantity a user cares about)
-    rng_ = np.random.default_rng(0)
-    pi, pt = rng_.integers(0, d1 * d2, 600), rng_.integers(0, T, 600)
-    y = ((mov - ref.mean_img[None]) / ref.std_img[None]).reshape(T, -1, order=kw.get("order", "F"))[pt, pi]
-    rec = np.einsum("pk,k,kp->p", np.asarray(pmd.u.tocsr()[pi] @ pmd.r), pmd.s, pmd.v[:, pt])
-    rec0 = np.einsum("pk,k,kp->p", np.asarray(ref.u.tocsr()[pi] @ ref.r), ref.s, ref.v[:, pt])
-    fig["fit"] = (float(np.mean((rec - y) ** 2)), float(np.mean((rec0 - y) ** 2)))
+    order = kw.get("order", "F")
+    fig["fit"] = (probe_fit(pmd, mov, ref.mean_img, ref.std_img, order), probe_fit(ref, mov, ref.mean_img, ref.std_img, order))
     say(f"   mean squared residual on 600 probes: {fig['fit'][0]:.4f} (HIP) / {fig['fit'][1]:.4f} (oracle)")
+    if "fits" in fig:
+        say("   the same for the other arithmetic forms: " + ", ".join(f"{k} {v:.4f}" for k, v in fig["fits"].items()))
     return fig
 
 
@@ -142,6 +173,18 @@ def _arbiter_distances(ctx, mov, block, frames, kw, pmd, diag, ref, say):
 
     arb, ref1 = run(fp64=True), run(lapack="single")
     out = {}
+    # Conditioning of the matrix the orthogonalisation diagonalises when R > frames (decomposition.py:974-999):
+    # C = right^T (U^T U) right.  Eigenvalues below ~eps32 lambda_max are not resolvable by ANY fp32 eigensolver, and the
+    # reference scales those directions by 1 / sqrt(|lambda|).
+    ua = arb.u.tocsr().astype(np.float64)
+    right = np.asarray(arb.diag["v_cropped"], dtype=np.float64)
+    cond = None
+    if ua.shape[1] > right.shape[1]:
+        lam_c = np.linalg.eigvalsh(right.T @ np.asarray((ua.T @ ua) @ right))
+        cond = float(lam_c[0] / lam_c[-1])
+        say(f"   R > frames: lambda_min / lambda_max of right^T U^T U right = {cond:.2e} (eps32 = {np.finfo(np.float32).eps:.2e})")
+    fits = {"arbiter fp64": probe_fit(arb, mov, ref.mean_img, ref.std_img, kw.get("order", "F")),
+            "oracle fp32 single-LAPACK": probe_fit(ref1, mov, ref.mean_img, ref.std_img, kw.get("order", "F"))}
     sides = {"HIP": (pmd, diag["tile_ranks"], PM.hip_cols(diag)), "oracle fp32": (ref, ref.diag["tile_ranks"], PM.oracle_cols(ref)),
              "oracle fp32 single-LAPACK": (ref1, ref1.diag["tile_ranks"], PM.oracle_cols(ref1))}
     ac = PM.oracle_cols(arb)
@@ -161,10 +204,55 @@ def _arbiter_distances(ctx, mov, block, frames, kw, pmd, diag, ref, say):
                      "s_signal": float(m["s_rel"][m["signal"]].max(initial=0.0)), "vt_signal": float(m["vt_row_err"][m["signal"]].max(initial=0.0))}
         say(f"   {name} vs arbiter fp64: passing-span s top-quarter {out[name]['span_top']:.2e} / all {out[name]['span_all']:.2e}, "
             f"U_data stable {m['u_data_err_stable']:.2e}, final s signal {out[name]['s_signal']:.2e}, Vt signal {out[name]['vt_signal']:.2e}")
-    return {"arbiter": out}
+    return {"arbiter": out, "fits": fits, "gram_cond": cond}
 
 
 _CASES = {c[0]: c for c in draw_cases(max(FUZZ_CASES) + 1)}
+# the second family (many tiles, R > frames): a well-conditioned draw, three with Gram eigenvalues at the rounding level
+# (5: the constant null direction + a failed Cholesky step - the fallback that once blew up; 20: where the reference's
+# own arithmetic ends at 12.6 / 55; 21: resolvable except for one direction)
+WIDE_SEED = 11
+WIDE_CASES = [4, 5, 20, 21]
+_WIDE = {c[0]: c for c in draw_wide_cases(max(WIDE_CASES) + 1, WIDE_SEED)}
+
+
+def check_case(fig):
+    """The assertions of one draw (shared with scripts/fuzz_sweep.py)."""
+    pmd, ref = fig["pmd"], fig["ref"]
+    assert np.all(np.isfinite(pmd.s)) and np.all(np.isfinite(pmd.v)) and np.all(np.isfinite(pmd.u.data)) and np.all(np.isfinite(pmd.r))
+    np.testing.assert_allclose(pmd.mean_img, ref.mean_img, rtol=1e-5)
+    np.testing.assert_allclose(pmd.var_img, ref.std_img, rtol=2e-4)
+    # tile ranks may differ only where a decision statistic sits within 1 % of its threshold
+    assert set(fig["rank_diff_tiles"].tolist()) <= set(np.nonzero(fig["knife"])[0].tolist()), fig["rank_diff_tiles"]
+    # fit to the data: as good as the oracle's, or - where fp32 loses the small half of the spectrum in EVERY implementation
+    # (R > frames with a few hundred frames, see DESIGN section 2) - not farther from the float64 result than the
+    # reference's own fp32 arithmetic
+    e1, e0 = fig["fit"]
+    unresolvable = fig.get("gram_cond") is not None and fig["gram_cond"] < 16 * np.finfo(np.float32).eps
+    if abs(e1 - e0) >= 0.05 * e0 + 1e-6:
+        fits = fig.get("fits")
+        assert fits is not None, fig["fit"]
+        ea, es = fits["arbiter fp64"], fits["oracle fp32 single-LAPACK"]
+        if unresolvable:
+            # no fp32 form is reliable here (profiles/r02_fuzz_wide.txt: the reference's arithmetic ends between 0.9 and 55
+            # where float64 gives 0.9); what is asserted is the absence of a blow-up (a fallback bug once gave 1400)
+            assert e1 <= 5.0 * ea, (fig["fit"], fits)
+        else:
+            assert abs(e1 - ea) <= 3.0 * max(abs(e0 - ea), abs(es - ea)) + 0.05 * ea, (fig["fit"], fits)
+    if len(fig["rank_diff_tiles"]) == 0:
+        assert pmd.r.shape == ref.r.shape and pmd.s.shape == ref.s.shape and pmd.v.shape == ref.v.shape
+        assert fig["measure"]["csr_equal"]
+        # distance to the float64 arbiter: HIP within a small multiple of the reference's own fp32 arithmetic
+        arb = fig["arbiter"]
+        # R > frames with eigenvalues of the orthogonalisation's Gram matrix at the fp32 rounding level: the global stage is
+        # not determined by fp32 arithmetic (every fp32 eigensolver returns different vectors for that part of the spectrum,
+        # the 1 / sqrt(|lambda|) scaling amplifies them: DESIGN section 2, profiles/r02_fuzz_wide.txt); the tile stage (U) and
+        # the fit to the data are still compared
+        keys = (("span_top", 2e-4), ("span_all", 5e-4), ("u_stable", 2e-5)) + (() if unresolvable else (("s_signal", 1e-4), ("vt_signal", 3e-4)))
+        if "HIP" in arb and len(arb) == 3:
+            for key, floor in keys:
+                worst_ref = max(arb["oracle fp32"][key], arb["oracle fp32 single-LAPACK"][key])
+                assert arb["HIP"][key] <= 3.0 * worst_ref + floor, (key, arb["HIP"][key], arb["oracle fp32"][key], arb["oracle fp32 single-LAPACK"][key])
 
 
 @pytest.mark.parametrize("case", FUZZ_CASES)
@@ -172,20 +260,12 @@ def test_fuzz_case(gpu_ctx, case):
     lines = []
     fig = run_case(gpu_ctx, *_CASES[case], out=lines.append)
     print("\n".join(lines))
-    pmd, ref = fig["pmd"], fig["ref"]
-    assert np.all(np.isfinite(pmd.s)) and np.all(np.isfinite(pmd.v)) and np.all(np.isfinite(pmd.u.data)) and np.all(np.isfinite(pmd.r))
-    np.testing.assert_allclose(pmd.mean_img, ref.mean_img, rtol=1e-5)
-    np.testing.assert_allclose(pmd.var_img, ref.std_img, rtol=2e-4)
-    # tile ranks may differ only where a decision statistic sits within 1 % of its threshold
-    assert set(fig["rank_diff_tiles"].tolist()) <= set(np.nonzero(fig["knife"])[0].tolist()), fig["rank_diff_tiles"]
-    e1, e0 = fig["fit"]
-    assert abs(e1 - e0) < 0.05 * e0 + 1e-6, fig["fit"]
-    if len(fig["rank_diff_tiles"]) == 0:
-        assert pmd.r.shape == ref.r.shape and pmd.s.shape == ref.s.shape and pmd.v.shape == ref.v.shape
-        assert fig["measure"]["csr_equal"]
-        # distance to the float64 arbiter: HIP within a small multiple of the reference's own fp32 arithmetic
-        arb = fig["arbiter"]
-        if "HIP" in arb and len(arb) == 3:
-            for key, floor in (("span_top", 2e-4), ("span_all", 5e-4), ("u_stable", 2e-5), ("s_signal", 1e-4), ("vt_signal", 3e-4)):
-                worst_ref = max(arb["oracle fp32"][key], arb["oracle fp32 single-LAPACK"][key])
-                assert arb["HIP"][key] <= 3.0 * worst_ref + floor, (key, arb["HIP"][key], arb["oracle fp32"][key], arb["oracle fp32 single-LAPACK"][key])
+    check_case(fig)
+
+
+@pytest.mark.parametrize("case", WIDE_CASES)
+def test_fuzz_wide_case(gpu_ctx, case):
+    lines = []
+    fig = run_case(gpu_ctx, *_WIDE[case], out=lines.append)
+    print("\n".join(lines))
+    check_case(fig)
