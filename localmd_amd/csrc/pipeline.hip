@@ -2,6 +2,7 @@
 // background rSVD.  Everything is enqueued on ctx->stream inside a caller-provided workspace;
 // nothing here allocates or synchronises.
 #include "pmd_internal.h"
+#include <algorithm>
 
 int pmd_tile_dpad(int d) {
   if (d > 2048) return -1;
@@ -18,6 +19,25 @@ long pmd_time_ld(long t) { return pmd_round_up(t, 64) + PMD_LD_SLACK; }
     int rc__ = (call);            \
     if (rc__ != PMD_OK) return rc__; \
   } while (0)
+
+// Orthonormal basis of the sketch's column space (jnp.linalg.qr at decomposition.py:64 / pmd_loader.py:58).  Householder QR
+// in LDS while the P x l matrix fits a workgroup's 160 KB (every default configuration); beyond that - large tiles with
+// spatial_avg_factor = 1 and a wide sketch, e.g. 30 x 40 pixels x 58 columns - CholeskyQR2 with the fp64 Gram / Cholesky
+// kernels of the whitening steps: the same Q up to the signs of its columns (QR is unique up to them), and everything
+// downstream (B = Q^T A, the SVD of B, U = Q W) is invariant under those signs.
+static int tile_sketch_basis(pmd_ctx* ctx, const float* Yt, long stride, int ld, int P, int l, float* Qt, double* gpart, double* nmat,
+                             int n) {
+  if (pmd_small_qr_fits(P, l)) return pmd_launch_small_qr(ctx, Yt, stride, ld, P, l, Qt, stride, ld, n);
+  const int nref = P < l ? P : l;
+  const float* src = Yt;
+  for (int pass = 0; pass < 2; ++pass) {
+    RUN(pmd_launch_tile_gram(ctx, src, stride, ld, P, n, 1, gpart));
+    RUN(pmd_launch_small_chol(ctx, gpart, 1, nref, 1e-12, nmat, n));
+    RUN(pmd_launch_tile_rowmix(ctx, src, stride, ld, nmat, 4096, nref, nref, Qt, stride, ld, P, n));
+    src = Qt;
+  }
+  return PMD_OK;
+}
 
 // ------------------------------------------------------------------------------------------
 // per-tile decomposition (decomposition.py:235-330 single_block_md, one window, + :501-523)
@@ -77,14 +97,17 @@ int pmd_tiles_decompose_impl(pmd_ctx* ctx, const float* Xf, long ldx, long n_row
   const int d = b1 * b2;
   if (r < 1 || r + 10 > 64) return pmd_fail(ctx, PMD_ERR_UNSUPPORTED, "pmd_tiles_decompose", "max_components must be in [1, 54]");
   if (a < 1 || t_crop % a != 0 || t_crop / a < 1) return pmd_fail(ctx, PMD_ERR_ARG, "pmd_tiles_decompose", "t_crop must be a positive multiple of temporal_avg_factor");
-  if (r > t_crop / a) return pmd_fail(ctx, PMD_ERR_ARG, "pmd_tiles_decompose", "max_components exceeds frames/temporal_avg_factor");
   if (ldv < pmd_time_ld(t_crop) || ldx < pmd_time_ld(t_crop)) return pmd_fail(ctx, PMD_ERR_ARG, "pmd_tiles_decompose", "leading dimension too small");
   pmd_arena ar(ws, ws_bytes);
   tiles_plan p;
   if (plan_tiles(ar, p, n, d, P, r, a, t_crop, ldv, n_rows) != PMD_OK)
     return pmd_fail(ctx, PMD_ERR_UNSUPPORTED, "pmd_tiles_decompose", "tile too large (max 2048 pixels)");
   if (ar.overflow) return pmd_fail(ctx, PMD_ERR_WORKSPACE, "pmd_tiles_decompose", "workspace too small");
-  if (r > p.nref) return pmd_fail(ctx, PMD_ERR_ARG, "pmd_tiles_decompose", "max_components exceeds pooled pixel count");
+  // max_components beyond the number of time bins or of pooled pixels: the reference's rSVD (decomposition.py:59-73) keeps
+  // its sketch of max_components + 10 columns and `u_final[:, :rank]` simply returns the min(rank, bins, pixels) columns
+  // that exist; everything downstream then works on that many components
+  if (r > p.nb) r = p.nb;
+  if (r > p.nref) r = p.nref;
   const long s64d = 64L * p.dpad, s64P = 64L * p.Ppad, s64b = 64L * p.ld_b, s64v = 64L * ldv;
   // PMD_TILE_WHITEN=eig restores the eigenvector form of the two pure orthonormalisation steps (A/B runs)
   static int whiten_mode = -1;
@@ -106,7 +129,7 @@ int pmd_tiles_decompose_impl(pmd_ctx* ctx, const float* Xf, long ldx, long n_row
                        omega_index_step, tn, p.nb, p.l, 1, p.omT + (long)t0 * s64b, p.ld_b, s64b));
   }
   RUN(pmd_launch_tile_xbt(ctx, p.abar, p.ld_b, nullptr, 0, P, P, p.omT, s64b, p.ld_b, p.yt, s64P, 0, p.Ppad, n, p.nb, 1));
-  RUN(pmd_launch_small_qr(ctx, p.yt, s64P, p.Ppad, P, p.l, p.qt, s64P, p.Ppad, n));
+  RUN(tile_sketch_basis(ctx, p.yt, s64P, p.Ppad, P, p.l, p.qt, p.gpart, p.nmat, n));
   RUN(pmd_launch_tile_atx(ctx, p.abar, p.ld_b, nullptr, 0, P, P, p.qt, s64P, p.Ppad, p.bm, s64b, p.ld_b, n, p.nb, 1));
   RUN(pmd_launch_tile_gram(ctx, p.bm, s64b, p.ld_b, p.nb, n, 1, p.gpart));
   RUN(pmd_launch_small_eig(ctx, p.gpart, 1, p.nref, 0, 0.0, p.nmat, p.lam, n));
@@ -218,7 +241,6 @@ int pmd_tiles_residual_impl(pmd_ctx* ctx, const float* Xw, long ldx, long n_rows
   const int d = b1 * b2;
   if (r < 1 || r + 10 > 64) return pmd_fail(ctx, PMD_ERR_UNSUPPORTED, "pmd_tiles_residual", "max_components must be in [1, 54]");
   if (a < 1 || L % a != 0 || L / a < 1) return pmd_fail(ctx, PMD_ERR_ARG, "pmd_tiles_residual", "window length must be a positive multiple of temporal_avg_factor");
-  if (r > L / a) return pmd_fail(ctx, PMD_ERR_ARG, "pmd_tiles_residual", "max_components exceeds window frames/temporal_avg_factor");
   if (ldx < pmd_time_ld(L)) return pmd_fail(ctx, PMD_ERR_ARG, "pmd_tiles_residual", "leading dimension too small");
   pmd_arena ar(ws, ws_bytes);
   resid_plan p;
@@ -238,20 +260,22 @@ int pmd_tiles_residual_impl(pmd_ctx* ctx, const float* Xw, long ldx, long n_rows
                        p.nb, p.l, 1, p.omT + (long)t0 * s64b, p.ld_b, s64b));
   }
   RUN(pmd_launch_tile_xbt(ctx, p.ar, p.ld_b, nullptr, 0, d, d, p.omT, s64b, p.ld_b, p.yt, s64d, 0, p.dpad, n, p.nb, 1));
-  RUN(pmd_launch_small_qr(ctx, p.yt, s64d, p.dpad, d, p.l, p.qt, s64d, p.dpad, n));
+  RUN(tile_sketch_basis(ctx, p.yt, s64d, p.dpad, d, p.l, p.qt, p.gpart, p.nmat, n));
   RUN(pmd_launch_tile_atx(ctx, p.ar, p.ld_b, nullptr, 0, d, d, p.qt, s64d, p.dpad, p.bm, s64b, p.ld_b, n, p.nb, 1));
   RUN(pmd_launch_tile_gram(ctx, p.bm, s64b, p.ld_b, p.nb, n, 1, p.gpart));
   RUN(pmd_launch_small_eig(ctx, p.gpart, 1, p.nref, 0, 0.0, p.nmat, p.lam, n));
-  RUN(pmd_launch_tile_rowmix(ctx, p.qt, s64d, p.dpad, p.nmat, 4096, p.nref, r, p.unew, s64d, p.dpad, d, n));
+  // new components of this window: min(max_components, bins, pixels) of them exist (see pmd_tiles_decompose_impl)
+  const int rn = std::min(r, std::min(p.nb, p.nref));
+  RUN(pmd_launch_tile_rowmix(ctx, p.qt, s64d, p.dpad, p.nmat, 4096, p.nref, rn, p.unew, s64d, p.dpad, d, n));
   // v = u^T (I - E E^T) X = utilde^T X with utilde = u - E (E^T u)   (decomposition.py:370-371, :379)
   RUN(pmd_launch_tile_cross_gram(ctx, Ucur, p.unew, s64d, p.dpad, d, p.nmat, n));
-  RUN(pmd_launch_tile_rowmix(ctx, Ucur, s64d, p.dpad, p.nmat, 4096, r, r, p.tmp, s64d, p.dpad, d, n));
+  RUN(pmd_launch_tile_rowmix(ctx, Ucur, s64d, p.dpad, p.nmat, 4096, r, rn, p.tmp, s64d, p.dpad, d, n));
   PMD_HIP(ctx, hipMemcpyAsync(p.util, p.unew, (size_t)n * s64d * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
   RUN(pmd_launch_tile_sub(ctx, p.util, p.tmp, s64d, p.dpad, d, n));
   RUN(pmd_launch_tile_atx(ctx, Xw, ldx, tile_pix, d, 0, d, p.util, s64d, p.dpad, p.vmat, s64L, p.ld_L, n, L, 2));
   // fitness, keep/discard scan, append behind the existing components
-  RUN(pmd_launch_stats_roughness(ctx, p.unew, s64d, p.dpad, b1, b2, p.vmat, s64L, p.ld_L, L, r, stats_out, n));
-  RUN(pmd_launch_tile_append(ctx, stats_out, r, thr_s, thr_t, max_fail, r, p.unew, Ucur, p.dpad, counts, good_out, keep_out, n));
+  RUN(pmd_launch_stats_roughness(ctx, p.unew, s64d, p.dpad, b1, b2, p.vmat, s64L, p.ld_L, L, rn, stats_out, n));
+  RUN(pmd_launch_tile_append(ctx, stats_out, rn, thr_s, thr_t, max_fail, r, p.unew, Ucur, p.dpad, counts, good_out, keep_out, n));
   return PMD_OK;
 }
 
@@ -322,7 +346,7 @@ int pmd_threshold_sim_impl(pmd_ctx* ctx, int b1, int b2, int t, int iters, uint6
     RUN(pmd_launch_rng(ctx, seed, PMD_STREAM_SIM_OMEGA, (uint32_t)it0, 1, nb, t, l, 1, p.omT, p.ld_t, s64t));
     RUN(pmd_launch_tile_xbt(ctx, p.noise, p.ld_t, nullptr, 0, d, d, p.omT, s64t, p.ld_t, p.ypart, XBT_SLICES * s64d, s64d, p.dpad, nb, t, XBT_SLICES));
     RUN(pmd_launch_reduce_slices(ctx, p.ypart, XBT_SLICES * s64d, s64d, XBT_SLICES, s64d, p.yt, s64d, nb));
-    RUN(pmd_launch_small_qr(ctx, p.yt, s64d, p.dpad, d, l, p.qt, s64d, p.dpad, nb));
+    RUN(tile_sketch_basis(ctx, p.yt, s64d, p.dpad, d, l, p.qt, p.gpart, p.nmat, nb));
     RUN(pmd_launch_tile_atx(ctx, p.noise, p.ld_t, nullptr, 0, d, d, p.qt, s64d, p.dpad, p.bm, s64t, p.ld_t, nb, t, 4));
     RUN(pmd_launch_tile_gram(ctx, p.bm, s64t, p.ld_t, t, nb, GRAM_SLICES, p.gpart));
     RUN(pmd_launch_small_eig(ctx, p.gpart, GRAM_SLICES, nref, 0, 0.0, p.nmat, p.lam, nb));

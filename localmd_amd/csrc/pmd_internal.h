@@ -42,6 +42,7 @@ int pmd_launch_tile_rowmix(pmd_ctx* ctx, const float* In, long in_tile_stride, l
                            int len, int n_tiles);
 
 // small_la.hip
+bool pmd_small_qr_fits(int P, int l);
 int pmd_launch_small_qr(pmd_ctx* ctx, const float* Yt, long y_tile_stride, int y_ld, int P, int l, float* Qt,
                         long q_tile_stride, int q_ld, int n_tiles);
 int pmd_launch_small_eig(pmd_ctx* ctx, const double* G, int slices, int n, int mode, double tol, double* Nout,

@@ -103,6 +103,12 @@ __global__ __launch_bounds__(256) void small_qr_kernel(const float* __restrict__
   }
 }
 
+// does the P x l matrix (fp32 storage at least) fit the 160 KB of LDS a workgroup can have?
+bool pmd_small_qr_fits(int P, int l) {
+  const size_t tail = (64 + 260) * sizeof(double) + 16;
+  return l <= 64 && (size_t)l * (P | 1) * sizeof(float) + tail <= 160 * 1024;
+}
+
 int pmd_launch_small_qr(pmd_ctx* ctx, const float* Yt, long y_tile_stride, int y_ld, int P, int l, float* Qt,
                         long q_tile_stride, int q_ld, int n_tiles) {
   pmd_prof_scope prof__(ctx, "small_qr");

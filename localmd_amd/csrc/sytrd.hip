@@ -1007,12 +1007,50 @@ int pmd_syevd_two_stage(pmd_ctx* ctx, int n, float* A, long lda, float* w, int* 
   return PMD_OK;
 }
 
+namespace {
+__global__ void widen_kernel(const float* __restrict__ src, long lds_, double* __restrict__ dst, long ldd, int n) {
+  const int r = blockIdx.y;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) dst[(long)r * ldd + c] = (double)src[(long)r * lds_ + c];
+}
+__global__ void narrow_kernel(const double* __restrict__ src, long lds_, float* __restrict__ dst, long ldd, int n) {
+  const int r = blockIdx.y;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) dst[(long)r * ldd + c] = (float)src[(long)r * lds_ + c];
+}
+}  // namespace
+
+// Small orders in double precision (rocSOLVER dsyevd on a widened copy, results rounded to fp32): what NumPy does for
+// float32 input, and the policy of the tile stage (Gram matrices diagonalised in fp64) carried up to the global stage
+// where it costs a few milliseconds.  The fp32 divide-and-conquer class loses two digits against QR-iteration / MRRR
+// solvers on the graded Gram spectra of this pipeline (profiles/r02_fuzz_wide.txt); in fp64 that is below fp32 rounding.
+static int syevd_f64(pmd_ctx* ctx, int n, float* A, long lda, float* w, int* info) {
+  pmd_prof_scope prof__(ctx, "rocsolver_dsyevd");
+  void* scratch = nullptr;
+  int rc = ctx_scratch(ctx, ((size_t)n * n + 2 * (size_t)n) * sizeof(double) + 4096, &scratch);
+  if (rc != PMD_OK) return rc;
+  pmd_arena ar(scratch, ctx->scratch_bytes);
+  double* Ad = ar.take_n<double>((size_t)n * n);
+  double* wd = ar.take_n<double>(n);
+  double* ed = ar.take_n<double>(n);
+  hipLaunchKernelGGL(widen_kernel, dim3((n + 255) / 256, n), dim3(256), 0, ctx->stream, A, lda, Ad, (long)n, n);
+  PMD_LAUNCH_CHECK(ctx, "widen_kernel");
+  PMD_BLAS(ctx, rocsolver_dsyevd(ctx->blas, rocblas_evect_original, rocblas_fill_lower, n, Ad, n, wd, ed, info));
+  hipLaunchKernelGGL(narrow_kernel, dim3((n + 255) / 256, n), dim3(256), 0, ctx->stream, Ad, (long)n, A, lda, n);
+  hipLaunchKernelGGL(narrow_kernel, dim3((n + 255) / 256, 1), dim3(256), 0, ctx->stream, wd, (long)n, w, (long)n, n);
+  PMD_LAUNCH_CHECK(ctx, "narrow_kernel");
+  return PMD_OK;
+}
+
 // Symmetric eigendecomposition, ascending eigenvalues; on exit memory row j of A is eigenvector j.
 // Only the row-major upper triangle of A (= column-major lower) is read.  work: n floats, info: device int.
 int pmd_syevd(pmd_ctx* ctx, int n, float* A, long lda, float* w, float* work, int* info) {
   const char* mode = getenv("PMD_SYEVD");
   const bool force_lib = mode && !strcmp(mode, "rocsolver");
   const bool force_own = mode && !strcmp(mode, "own");
+  if (!mode || !strcmp(mode, "f64")) {
+    static int f64_max = -1;
+    if (f64_max < 0) { const char* e_ = getenv("PMD_SYEVD_F64_MAX"); f64_max = e_ ? atoi(e_) : 512; }
+    if (n >= 1 && (n <= f64_max || mode)) return syevd_f64(ctx, n, A, lda, w, info);
+  }
   const bool own = !force_lib && (force_own || n >= 192) && n >= 3 && lda % 4 == 0 && lda >= pmd_round_up(n, 4) && !((uintptr_t)A & 15);
   if (!own) {
     pmd_prof_scope prof__(ctx, "rocsolver_ssyevd");

@@ -281,6 +281,7 @@ def _tiles_decompose(ctx, args, ws, hook_geom, temporal_denoiser, spatial_denois
     if rc != 0:
         raise ValueError("pmd_tiles_hook_offsets failed ({})".format(rc))
     flat = ws.view(torch.uint8).reshape(-1)
+    r = min(r, t_crop // a_f, P_pool, r + 10)   # the components that exist (pmd_tiles_decompose: bins / pooled pixels may be fewer)
     vds = flat[off_v.value:off_v.value + n * 64 * ldv * 4].view(torch.float32).view(n, 64, ldv)[:, :r, :t_crop]
     s_arr = flat[off_s.value:off_s.value + n * 64 * dpad * 4].view(torch.float32).view(n, 64, dpad)[:, :r, :b1 * b2]
     ctx.call("pmd_tiles_decompose_staged", *args, ptr(ws), ws.numel(), 1)

@@ -67,6 +67,38 @@ def draw_wide_cases(n_cases, seed):
     return out
 
 
+def draw_option_cases(n_cases, seed):
+    """Draws over the option space the first two families leave out: large max_components / background_rank, blocks up to
+    40 x 40, rank_prune, pixel_weighting, window_chunks, integer and float64 input arrays, other noise levels."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for case in range(n_cases):
+        b1, b2 = (int(2 * rng.integers(5, 21)) for _ in range(2))
+        d1 = int(rng.integers(b1, int(2.5 * b1) + 8))
+        d2 = int(rng.integers(b2, int(2.5 * b2) + 8))
+        taf = int(rng.choice([1, 2, 5, 10]))
+        saf = int(rng.choice([1, 2, 4]))
+        T = int(rng.integers(300, 700))
+        frames = T if rng.random() < 0.6 else int(rng.integers(260, T))
+        pooled = (-(-b1 // saf)) * (-(-b2 // saf))
+        r_max = min(54, frames // taf, pooled)
+        kw = dict(max_components=int(rng.integers(min(8, r_max), r_max + 1)), background_rank=int(rng.integers(0, 21)),
+                  temporal_avg_factor=taf, spatial_avg_factor=saf, order=str(rng.choice(["F", "C"])),
+                  compute_normalizer=bool(rng.random() < 0.8), max_consecutive_failures=int(rng.choice([1, 2, 3])))
+        if rng.random() < 0.3:
+            kw["rank_prune"] = True
+            kw["rank_prune_factor"] = float(rng.choice([0.3, 0.5, 0.7]))
+        if rng.random() < 0.3:
+            kw["pixel_weighting"] = (0.5 + np.random.default_rng(seed * 1000 + case).random((d1, d2))).astype(np.float32)
+        if rng.random() < 0.25 and frames >= 400:
+            wc = int(frames // 2 // taf * taf)
+            if wc >= 100:
+                kw["window_chunks"] = wc
+        extra = {"noise": float(rng.choice([0.5, 1.0, 2.0])), "dtype": str(rng.choice(["float32", "float32", "uint16", "float64"]))}
+        out.append((case, T, d1, d2, b1, b2, frames, kw, extra))
+    return out
+
+
 def passing_span_singular_values(res, passed, n_tile_cols, mov, mean_img, std_img, order):
     """Singular values (float64) of the standardised movie projected on span(U[:, passing tile columns + background])."""
     T = mov.shape[0]
@@ -93,13 +125,23 @@ def probe_fit(res, mov, mean_img, std_img, order, n_probes=600):
     return float(np.mean((rec - y) ** 2))
 
 
-def run_case(ctx, case, T, d1, d2, b1, b2, frames, kw, out=None):
+def run_case(ctx, case, T, d1, d2, b1, b2, frames, kw, extra=None, out=None):
     """Returns a dict of the measured figures of one draw (and reports them through `out`)."""
     say = out or (lambda s: None)
-    mov = tp._movie(T, d1, d2, seed=1000 + case)
+    if extra:
+        from localmd_amd.synthetic import make_movie
+
+        mov = make_movie(T, d1, d2, seed=1000 + case, noise=extra["noise"])
+        if extra["dtype"] == "uint16":
+            mov = np.clip(np.round(mov * 20.0), 0, 65535).astype(np.uint16)
+        else:
+            mov = mov.astype(extra["dtype"])
+    else:
+        mov = tp._movie(T, d1, d2, seed=1000 + case)
     # injected thresholds between the statistics of signal components and of noise (as in scripts/fuzz_parity.py)
     pmd, diag, ref = tp._compare_full(ctx, mov, (b1, b2), frames, thresholds=(1.0, 1.7), **kw)
-    say(f"case {case}: T={T} fov={d1}x{d2} block={b1}x{b2} frames={frames} {kw}")
+    shown = {k: (f"array{v.shape}" if isinstance(v, np.ndarray) else v) for k, v in kw.items()}
+    say(f"case {case}: T={T} fov={d1}x{d2} block={b1}x{b2} frames={frames} {shown} {extra or ''}")
     fig = {"pmd": pmd, "diag": diag, "ref": ref}
     dr = diag["tile_ranks"].astype(int) - ref.diag["tile_ranks"].astype(int)
     thr = diag["thresholds"]
@@ -214,6 +256,13 @@ _CASES = {c[0]: c for c in draw_cases(max(FUZZ_CASES) + 1)}
 WIDE_SEED = 11
 WIDE_CASES = [4, 5, 20, 21]
 _WIDE = {c[0]: c for c in draw_wide_cases(max(WIDE_CASES) + 1, WIDE_SEED)}
+# the third family (the rest of the option space; 3 seeds x 48 draws swept with scripts/fuzz_sweep.py).  Seed 22: draws 3 and 10 had Vt errors of 7e-4 / 1e-3 on signal components
+# while the global stage still ran its small eigenproblems in fp32 divide and conquer; draws 13 and 45 (30 x 40 and 36 x 40
+# pixel tiles, spatial_avg_factor = 1, 58 / 57 sketch columns) need the CholeskyQR2 form of the sketch basis.  Seed 21:
+# rank_prune + float64 input at max_components = 47; rank_prune + pixel_weighting on uint16 input.
+# Seed 23, draw 11: max_components = 30 with 27 time bins per window (the reference's slicing returns 27 components).
+OPTION_CASES = [(22, 3), (22, 10), (22, 13), (22, 45), (21, 7), (21, 16), (23, 11)]
+_OPTION = {(sd, c[0]): c for sd in (21, 22, 23) for c in draw_option_cases(48, sd)}
 
 
 def check_case(fig):
@@ -267,5 +316,13 @@ def test_fuzz_case(gpu_ctx, case):
 def test_fuzz_wide_case(gpu_ctx, case):
     lines = []
     fig = run_case(gpu_ctx, *_WIDE[case], out=lines.append)
+    print("\n".join(lines))
+    check_case(fig)
+
+
+@pytest.mark.parametrize("seed,case", OPTION_CASES)
+def test_fuzz_option_case(gpu_ctx, seed, case):
+    lines = []
+    fig = run_case(gpu_ctx, *_OPTION[(seed, case)], out=lines.append)
     print("\n".join(lines))
     check_case(fig)

@@ -383,7 +383,42 @@ def test_sytrd_eigenvalues_2500(gpu_ctx):
     np.testing.assert_array_equal(e, e2)
 
 
-@pytest.mark.parametrize("n,force", [(150, True), (301, False), (1200, False)])
+@pytest.mark.parametrize("n", [3, 40, 72, 191, 512])
+def test_syevd_small_orders_in_double(gpu_ctx, n):
+    """Orders <= 512 (PMD_SYEVD_F64_MAX) are diagonalised in double precision and rounded: the result is the correctly
+    rounded eigendecomposition of the fp32 matrix - graded spectrum, small eigenvalues to high RELATIVE accuracy."""
+    torch = _t()
+    ctx = gpu_ctx
+    rng = np.random.default_rng(n)
+    q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    lam = np.geomspace(1e6, 1.0, n)
+    S = ((q * lam) @ q.T).astype(np.float32)
+    S = np.triu(S) + np.triu(S, 1).T
+    ld = (n + 3) // 4 * 4
+    buf = np.zeros((n, ld), dtype=np.float32)
+    buf[:, :n] = S
+    Sd = dev(ctx, buf)
+    w = torch.empty(n, dtype=torch.float32, device=ctx.device)
+    work = torch.empty(n, dtype=torch.float32, device=ctx.device)
+    info = torch.zeros(4, dtype=torch.int32, device=ctx.device)
+    ctx.profile_enable(True)
+    ctx.call("pmdk_syevd", n, P(Sd), ld, P(w), P(work), P(info))
+    ctx.sync()
+    prof = ctx.profile_summary()
+    ctx.profile_enable(False)
+    assert "rocsolver_dsyevd" in prof and "sytrd" not in prof, prof
+    assert int(info[0]) == 0
+    w64, e64 = np.linalg.eigh(S.astype(np.float64))
+    wv = w.cpu().numpy().astype(np.float64)
+    E = Sd.cpu().numpy()[:, :n].astype(np.float64)
+    np.testing.assert_allclose(wv, w64, rtol=3e-7, atol=0)
+    # P = E / sqrt(lambda): the quantity the pipeline forms (decomposition.py:990-996); an fp32 divide-and-conquer solver
+    # leaves 1e-2 ... 1e-1 here
+    Pm = E.T / np.sqrt(wv)[None, :]
+    assert np.abs(Pm.T @ S.astype(np.float64) @ Pm - np.eye(n)).max() < 5e-4
+
+
+@pytest.mark.parametrize("n,force", [(150, True), (301, True), (1200, False)])
 def test_syevd_own_path(gpu_ctx, n, force, monkeypatch):
     torch = _t()
     ctx = gpu_ctx

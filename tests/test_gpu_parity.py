@@ -405,6 +405,34 @@ def test_full_pipeline_multi_window_residual(gpu_ctx):
     assert np.any(ref.diag["tile_ranks"] > first)
 
 
+def test_full_pipeline_max_components_beyond_time_bins(gpu_ctx):
+    """max_components larger than frames / temporal_avg_factor: the reference's rSVD keeps its (max_components + 10)-column
+    sketch and returns the components that exist (decomposition.py:59-73, `u_final[:, :rank]`); no error."""
+    mov = _movie(300, 44, 40, seed=8)
+    # (cut-offs injected between the statistics of signal and of noise components: with 30 bins per tile the simulated
+    # ones sit inside the noise distribution and the decisions of the noise components become coin flips on both sides)
+    pmd, diag, ref = _compare_full(gpu_ctx, mov, (22, 20), 300, max_components=40, background_rank=2, thresholds=(1.0, 1.7),
+                                   temporal_avg_factor=10)
+    assert diag["tile_ranks"].max() <= 30
+    np.testing.assert_array_equal(diag["tile_ranks"], ref.diag["tile_ranks"])
+    assert pmd.s.shape == ref.s.shape
+    # Structure and fit, not the element-wise classes of _check_full: the standardised traces sum to zero, so the binned
+    # tile has rank 29 and its 30th left vector is LAPACK's arbitrary completion in the reference and the zero vector here
+    # (DESIGN section 2, numerical policy); through V_ds that adds one arbitrary direction to the row space the final tile
+    # SVD works in, which moves every later quantity by ~1e-3 on either side.
+    assert pmd.u.shape == ref.u.shape and pmd.r.shape == ref.r.shape and pmd.v.shape == ref.v.shape
+    np.testing.assert_array_equal(pmd.u.indptr, ref.u.indptr)
+    np.testing.assert_array_equal(pmd.u.indices, ref.u.indices)
+    assert np.all(np.isfinite(pmd.r)) and np.all(np.isfinite(pmd.v)) and np.all(np.isfinite(pmd.s))
+    k = len(ref.s) // 4
+    np.testing.assert_allclose(pmd.s[:k], ref.s[:k], rtol=5e-3)
+    rng = np.random.default_rng(0)
+    pi, pt = rng.integers(0, 44 * 40, 500), rng.integers(0, 300, 500)
+    y = ((mov - ref.mean_img[None]) / ref.std_img[None]).reshape(300, -1, order="F")[pt, pi]
+    fit = [float(np.mean((np.einsum("pk,k,kp->p", np.asarray(x.u.tocsr()[pi] @ x.r), x.s, x.v[:, pt]) - y) ** 2)) for x in (pmd, ref)]
+    assert abs(fit[0] - fit[1]) < 0.02 * fit[1], fit
+
+
 def test_full_pipeline_rank_prune(gpu_ctx):
     """rank_prune=True (decomposition.py:861-877): the right matrix is v_cropped times a Gaussian matrix
     (device stream PRUNE, handed to the oracle as is)."""
