@@ -481,11 +481,19 @@ int pmd_launch_tile_xbt(pmd_ctx* ctx, const float* X, long ldx, const int* pix, 
   if (n_tiles <= 0 || T <= 0) return PMD_OK;
   const int n_groups = (T + 15) / 16;
   if (slices < 1) slices = 1;
+  const int slices_asked = slices;
   if (slices > n_groups) slices = n_groups;
   const int gps = (n_groups + slices - 1) / slices;
   slices = (n_groups + gps - 1) / gps;
   const int mtiles = (d + 15) / 16;
   if (s_ld < 16 * mtiles) return pmd_fail(ctx, PMD_ERR_ARG, "tile_xbt", "s_ld too small");
+  if (slices < slices_asked && s_slice_stride > 0) {
+    // Short rows (T <= 48, 65-96 or 129-144 with four slices): fewer slices have work than the caller's buffer holds, and
+    // the caller sums all of them.  The slices without work are cleared here (found by the seeded fuzz with poisoned
+    // allocations: a 133-frame movie picked up stale workspace contents through the Gram matrix of V_ds).
+    PMD_HIP(ctx, hipMemset2DAsync(S + (long)slices * s_slice_stride, (size_t)s_tile_stride * sizeof(float), 0,
+                                  (size_t)(slices_asked - slices) * s_slice_stride * sizeof(float), (size_t)n_tiles, ctx->stream));
+  }
   // M tiles per wave: spread small tiles over the four waves, 7 per wave (112 accumulator VGPRs) at most
 #define XBT_LAUNCH(MPW_)                                                                                              \
   {                                                                                                                   \

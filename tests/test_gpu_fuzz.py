@@ -99,6 +99,28 @@ def draw_option_cases(n_cases, seed):
     return out
 
 
+def draw_edge_cases(n_cases, seed):
+    """Draws at the edges of the argument space: fewer than 256 frames (one Welch segment), FOV equal to or barely larger
+    than a block, frame counts that are no multiple of the temporal factor, one or two components, background ranks
+    around the number of bins, odd and too-small blocks (both sides must refuse the same inputs)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for case in range(n_cases):
+        b1, b2 = (int(rng.choice([8, 10, 10, 11, 12, 12, 14, 16, 20, 24])) for _ in range(2))
+        d1 = int(rng.choice([b1, b1 + 1, b1 + b1 // 2, 2 * b1 - 1, 2 * b1, 2 * b1 + 3]))
+        d2 = int(rng.choice([b2, b2 + 1, b2 + b2 // 2, 2 * b2 - 1, 2 * b2, 2 * b2 + 3]))
+        taf = int(rng.choice([1, 2, 3, 4, 7, 10]))
+        T = int(rng.integers(40, 320))
+        frames = int(rng.choice([T, T, T, T + 5, max(8, T // 2), max(8, T - 1), max(8, T - 1), taf - 1 if taf > 1 else 1]))
+        kw = dict(max_components=int(rng.choice([1, 2, 3, 5, 20])), background_rank=int(rng.choice([0, 1, 2, 8, 30])),
+                  temporal_avg_factor=taf, spatial_avg_factor=int(rng.choice([1, 2, 3, 5])), order=str(rng.choice(["F", "C"])),
+                  compute_normalizer=bool(rng.random() < 0.7), max_consecutive_failures=int(rng.choice([1, 2])))
+        if rng.random() < 0.2:
+            kw["window_chunks"] = int(rng.choice([taf * 5, taf * 13, frames + 1, max(1, frames // 2)]))
+        out.append((case, T, d1, d2, b1, b2, frames, kw, {"noise": 1.0, "dtype": "float32"}))
+    return out
+
+
 def passing_span_singular_values(res, passed, n_tile_cols, mov, mean_img, std_img, order):
     """Singular values (float64) of the standardised movie projected on span(U[:, passing tile columns + background])."""
     T = mov.shape[0]
@@ -109,6 +131,8 @@ def passing_span_singular_values(res, passed, n_tile_cols, mov, mean_img, std_im
     # step is the identity and its column of Q a vector of the orthogonal complement that depends on the signs of
     # rounding-level pivots - on sparse columns those differ between two runs that agree to 1e-7.
     keep &= np.asarray(np.abs(u).sum(axis=0)).reshape(-1) > 0
+    if not keep.any():
+        return np.zeros(0), 0
     q, _ = np.linalg.qr(np.asarray(u[:, keep].todense(), dtype=np.float64))
     y = ((mov.astype(np.float64) - mean_img[None]) / std_img[None]).reshape(T, -1, order=order).T
     return np.linalg.svd(q.T @ y, compute_uv=False), int(keep.sum())
@@ -175,8 +199,8 @@ def run_case(ctx, case, T, d1, d2, b1, b2, frames, kw, extra=None, out=None):
         sb, _ = passing_span_singular_values(ref, both, ntc, mov, mean64, std64, kw.get("order", "F"))
         relp = np.abs(sa - sb) / sb
         kq = max(1, len(sa) // 4)
-        fig["span_s_rel_all"], fig["span_s_rel_top"] = float(relp.max()), float(relp[:kq].max())
-        say(f"   projected on the {na} passing columns (+ background): s rel diff max {relp.max():.2e} over all {len(sa)}, top-quarter {relp[:kq].max():.2e}")
+        fig["span_s_rel_all"], fig["span_s_rel_top"] = float(relp.max(initial=0.0)), float(relp[:kq].max(initial=0.0))
+        say(f"   projected on the {na} passing columns (+ background): s rel diff max {fig['span_s_rel_all']:.2e} over all {len(sa)}, top-quarter {fig['span_s_rel_top']:.2e}")
         if len(bad):
             # where the offending values sit: next to the smallest singular values of the passing span = noise level
             say(f"   offending values {np.round(ref.s[bad], 1).tolist()} vs the passing span's smallest value {sb[-1]:.1f} and median {np.median(sb):.1f}")
@@ -242,7 +266,7 @@ def _arbiter_distances(ctx, mov, block, frames, kw, pmd, diag, ref, say):
         sb, _ = passing_span_singular_values(arb, both, ntc, mov, mean64, std64, order)
         relp = np.abs(sa - sb) / sb
         m = PM.measure(res, arb, cols, ac, ntc)
-        out[name] = {"span_top": float(relp[:max(1, len(sa) // 4)].max()), "span_all": float(relp.max()), "u_stable": m["u_data_err_stable"],
+        out[name] = {"span_top": float(relp[:max(1, len(sa) // 4)].max(initial=0.0)), "span_all": float(relp.max(initial=0.0)), "u_stable": m["u_data_err_stable"],
                      "s_signal": float(m["s_rel"][m["signal"]].max(initial=0.0)), "vt_signal": float(m["vt_row_err"][m["signal"]].max(initial=0.0))}
         say(f"   {name} vs arbiter fp64: passing-span s top-quarter {out[name]['span_top']:.2e} / all {out[name]['span_all']:.2e}, "
             f"U_data stable {m['u_data_err_stable']:.2e}, final s signal {out[name]['s_signal']:.2e}, Vt signal {out[name]['vt_signal']:.2e}")

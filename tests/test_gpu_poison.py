@@ -1,0 +1,126 @@
+"""
+No read of uninitialised device memory: the same decomposition with every buffer the host driver allocates (torch.empty,
+the context's workspaces) filled with NaN patterns beforehand must give bit-identical results.  (Found by the seeded fuzz:
+a 133-frame movie picked up stale workspace contents - `tile_xbt` launched fewer time slices than its caller summed.)
+"""
+import contextlib
+
+import numpy as np
+import pytest
+
+import tests.test_gpu_fuzz as F
+from localmd_amd.synthetic import make_movie
+
+pytestmark = pytest.mark.gpu
+
+
+@contextlib.contextmanager
+def poisoned_allocations():
+    import torch
+
+    orig = torch.empty
+
+    def empty(*a, **k):
+        t = orig(*a, **k)
+        if t.is_cuda and t.numel() > 0:
+            if t.dtype in (torch.float32, torch.float64):
+                t.fill_(float("nan"))
+            elif t.dtype == torch.uint8:
+                t.fill_(0xFF)          # a NaN pattern for the fp32 / fp64 views of a byte workspace, -1 for the int views
+            elif t.dtype in (torch.int32, torch.int64):
+                t.fill_(0x3FFFFFF0)
+        return t
+
+    torch.empty = empty
+    try:
+        yield
+    finally:
+        torch.empty = orig
+
+
+def _cases():
+    pick = [("edge", 32, 80, 6), ("edge", 31, 80, 3), ("base", 1, 40, 9), ("wide", 11, 24, 5), ("wide", 11, 24, 4),
+            ("options", 22, 48, 13), ("options", 21, 24, 7), ("options", 23, 48, 11), ("options", 21, 24, 8), ("options", 21, 24, 16)]
+    fam = {"base": F.draw_cases, "wide": F.draw_wide_cases, "options": F.draw_option_cases, "edge": F.draw_edge_cases}
+    out = []
+    for name, seed, n, case in pick:
+        c = [c for c in fam[name](n, seed) if c[0] == case][0]
+        out.append(pytest.param(c, id=f"{name}-{seed}-{case}"))
+    return out
+
+
+@pytest.mark.parametrize("c", _cases())
+@pytest.mark.parametrize("simulate", [False, True])
+def test_results_do_not_depend_on_buffer_contents(gpu_ctx, c, simulate):
+    import localmd_amd
+    from localmd_amd import decomposition as Dm
+
+    if simulate and c[0] % 2:      # the threshold simulation on half of the draws
+        pytest.skip("simulation covered by the other half")
+    case, T, d1, d2, b1, b2, frames, kw = c[:8]
+    extra = c[8] if len(c) > 8 else {"noise": 1.0, "dtype": "float32"}
+    mov = make_movie(T, d1, d2, seed=1000 + case, noise=extra["noise"])
+    Dm.QUIET = True
+    thr = dict(sim_iters=6) if simulate else dict(thresholds=(1.0, 1.7))
+
+    def run():
+        np.random.seed(7)
+        return localmd_amd.localmd_decomposition(mov, (b1, b2), frames, seed=123, ctx=gpu_ctx, **thr, **kw)
+
+    clean = run()
+    gpu_ctx.release_workspace()
+    with poisoned_allocations():
+        pois = run()
+    gpu_ctx.release_workspace()
+    for name in ("s", "r", "v"):
+        a, b = np.asarray(getattr(clean, name)), np.asarray(getattr(pois, name))
+        assert a.shape == b.shape and np.array_equal(a, b), name
+    ua, ub = clean.u.tocsr(), pois.u.tocsr()
+    assert np.array_equal(ua.indptr, ub.indptr) and np.array_equal(ua.indices, ub.indices) and np.array_equal(ua.data, ub.data)
+    assert np.array_equal(clean.mean_img, pois.mean_img) and np.array_equal(clean.var_img, pois.var_img)
+
+
+def _same(a, b):
+    for name in ("s", "r", "v"):
+        x, y = np.asarray(getattr(a, name)), np.asarray(getattr(b, name))
+        assert x.shape == y.shape and np.array_equal(x, y), name
+    ua, ub = a.u.tocsr(), b.u.tocsr()
+    assert np.array_equal(ua.indptr, ub.indptr) and np.array_equal(ua.indices, ub.indices) and np.array_equal(ua.data, ub.data)
+
+
+@pytest.mark.parametrize("variant", ["batched", "single_copy", "hooks", "chol_route", "headline_like"])
+def test_memory_plans_hooks_and_routes_with_poisoned_buffers(gpu_ctx, variant):
+    """The same check on the memory plan of the 84 GB workloads (tile batches, single standardised copy), the staged tile
+    pipeline around denoiser hooks, the row-sharded Cholesky route of the global stage, and a cut-down headline regime
+    (R > frames, own eigensolver beyond the double-precision limit of order 512)."""
+    import localmd_amd
+    from localmd_amd import decomposition as Dm
+    import tests.test_gpu_parity as tp
+
+    Dm.QUIET = True
+    if variant == "batched":
+        mov, blk, kw = tp._movie(300, 70, 80, seed=3), (10, 10), dict(max_components=8, background_rank=3, tile_batch_bytes=1, sim_iters=6)
+    elif variant == "single_copy":
+        mov, blk, kw = tp._movie(500, 60, 70, seed=4), (20, 20), dict(max_components=6, background_rank=3, tile_batch_bytes=1, single_copy=True, sim_iters=6)
+    elif variant == "hooks":
+        mov, blk = tp._movie(600, 40, 50, seed=21), (20, 20)
+        kw = dict(max_components=6, background_rank=2, sim_iters=6, temporal_denoiser=tp._smooth_time, spatial_denoiser=tp._smooth_space)
+    elif variant == "chol_route":
+        mov, blk, kw = tp._movie(300, 70, 80, seed=12), (10, 10), dict(max_components=8, background_rank=3, sim_iters=6)
+    else:
+        mov, blk, kw = tp._movie(700, 128, 128, seed=13), (16, 16), dict(max_components=10, background_rank=4, sim_iters=6)
+
+    def run():
+        np.random.seed(7)
+        return localmd_amd.localmd_decomposition(mov, blk, mov.shape[0], seed=5, ctx=gpu_ctx, return_diagnostics=True, **kw)
+
+    (clean, dc) = run()
+    gpu_ctx.release_workspace()
+    with poisoned_allocations():
+        (pois, dp) = run()
+    gpu_ctx.release_workspace()
+    if variant == "chol_route":
+        assert dc["orthogonalizer"] == "cholesky" and dc["rank_before"] > mov.shape[0], (dc["orthogonalizer"], dc["rank_before"])
+    if variant == "headline_like":
+        assert dc["rank_before"] > mov.shape[0] and dc["eig_order"] > 512, (dc["rank_before"], dc["eig_order"])
+    _same(clean, pois)
