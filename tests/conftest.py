@@ -13,6 +13,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "slow: minutes of CPU oracle work; runs only with PMD_RUN_SLOW=1")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _poison_all_allocations():
+    """PMD_TEST_POISON=1: the whole session runs with every torch.empty device buffer pre-filled with NaN patterns (a read of
+    uninitialised memory then shows up as a NaN or a failed comparison in whatever test exercises it)."""
+    if not os.environ.get("PMD_TEST_POISON"):
+        yield
+        return
+    from tests.test_gpu_poison import poisoned_allocations
+
+    with poisoned_allocations():
+        yield
+
+
 @pytest.fixture(scope="session")
 def gpu_ctx():
     import torch
