@@ -80,6 +80,10 @@ class PMDArray:
         fidx = np.arange(self.num_frames)[self._as_list(tkey)].reshape(-1)
         n_sel, nf = int(sel.size), int(fidx.size)
         out = np.empty((nf, n_sel), dtype=np.float32)
+        if n_sel == 0:
+            # an empty spatial selection: the reference's reshape cannot infer the frame axis and raises (pmdarray.py:165);
+            # the same statement, so the same ValueError, here
+            np.empty((0, nf), dtype=np.float32).reshape(fov + (-1,), order=self.order)
         if n_sel == 0 or nf == 0:
             return out.reshape((nf,) + fov).squeeze()
         rcols, rp = dv["rs"].shape

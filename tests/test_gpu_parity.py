@@ -609,10 +609,15 @@ def test_pmdarray_device_expansion_matches_host(gpu_ctx, order):
             g = pmd[k if len(k) > 1 else k[0]]
             assert g.shape == h.shape and g.dtype == h.dtype == np.float32, (k, g.shape, h.shape)
             np.testing.assert_allclose(g, h, rtol=2e-5, atol=2e-5 * max(1.0, float(np.abs(h).max()) if h.size else 1.0))
+        # an empty spatial selection is refused by the reference's reshape (pmdarray.py:165): same exception on the device path
+        with pytest.raises(ValueError):
+            pmd[3, 5:5, :]
     finally:
         pmd.to_host()
     assert pmd._dev is None
     np.testing.assert_array_equal(pmd[5], host[1])
+    with pytest.raises(ValueError):
+        pmd[3, 5:5, :]
 
 
 def _check_structure_and_fit(pmd, diag, ref, mov):
