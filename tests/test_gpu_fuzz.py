@@ -121,6 +121,44 @@ def draw_edge_cases(n_cases, seed):
     return out
 
 
+def draw_medium_cases(n_cases, seed):
+    """Fewer, larger draws (FOV around 100-160 pixels a side, 1000-2500 frames): beyond the thresholds of the small families - the
+    library's own eigensolver (orders above 512), the blocked Cholesky, split-K products, batches of tiles."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for case in range(n_cases):
+        b1, b2 = (int(2 * rng.integers(8, 17)) for _ in range(2))
+        d1 = int(rng.integers(3 * b1, 5 * b1))
+        d2 = int(rng.integers(3 * b2, 5 * b2))
+        taf = int(rng.choice([2, 5, 10]))
+        T = int(rng.integers(1000, 2500))
+        frames = T if rng.random() < 0.6 else int(rng.integers(700, T))
+        kw = dict(max_components=int(rng.integers(8, 21)), background_rank=int(rng.integers(0, 9)), temporal_avg_factor=taf,
+                  spatial_avg_factor=int(rng.choice([1, 2])), order=str(rng.choice(["F", "C"])),
+                  compute_normalizer=True, max_consecutive_failures=int(rng.choice([1, 1, 2])))
+        out.append((case, T, d1, d2, b1, b2, frames, kw, {"noise": float(rng.choice([0.5, 1.0])), "dtype": "float32"}))
+    return out
+
+
+def draw_tall_cases(n_cases, seed):
+    """Config-2-like draws: around a thousand small tiles and 600-1500 frames, R several times the number of frames (the
+    row-sharded Cholesky route with the library's own eigensolver at orders 600-1500)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for case in range(n_cases):
+        b1, b2 = (int(2 * rng.integers(5, 8)) for _ in range(2))
+        d1 = int(rng.integers(150, 220))
+        d2 = int(rng.integers(150, 220))
+        taf = int(rng.choice([2, 5, 10]))
+        T = int(rng.integers(600, 1500))
+        frames = T if rng.random() < 0.7 else int(rng.integers(500, T))
+        kw = dict(max_components=int(rng.integers(6, 11)), background_rank=int(rng.integers(0, 6)), temporal_avg_factor=taf,
+                  spatial_avg_factor=int(rng.choice([1, 2])), order=str(rng.choice(["F", "C"])),
+                  compute_normalizer=True, max_consecutive_failures=1)
+        out.append((case, T, d1, d2, b1, b2, frames, kw, {"noise": 1.0, "dtype": "float32"}))
+    return out
+
+
 def passing_span_singular_values(res, passed, n_tile_cols, mov, mean_img, std_img, order):
     """Singular values (float64) of the standardised movie projected on span(U[:, passing tile columns + background])."""
     T = mov.shape[0]
