@@ -1220,7 +1220,7 @@ __global__ void tril_mask_kernel(float* __restrict__ A, long ld, int n) {
 }
 
 size_t pmd_orthogonalize_chol_workspace_bytes_impl(int Rc, int m) {
-  return (size_t)m * Rc * sizeof(float) + ((size_t)m + CHOL_NB) * CHOL_NB * sizeof(float) + 16384;
+  return std::max((size_t)m * Rc * sizeof(float), pmd_chol_inverse_workspace_bytes_impl(m)) + ((size_t)m + CHOL_NB) * CHOL_NB * sizeof(float) + 16384;
 }
 
 // C (row-major lower block triangle, the part the Cholesky step reads) = M^T GM over `rows` rows of both.
@@ -1245,8 +1245,48 @@ int pmd_gram_mtgm_impl(pmd_ctx* ctx, const float* M, int rows, int m, long ldm, 
   return PMD_OK;
 }
 
+// Small orders in double precision (the policy of pmd_syevd, sytrd.hip: global-stage problems up to order 512 are factorised
+// in fp64 and rounded).  The Cholesky route amplifies the factorisation error by the condition number of C, which the
+// reference's rank_prune and R > frames routes drive to 1e5 ... 1e7: in fp32 the signal singular values of such draws came
+// out 27 % off where NumPy's (double-precision LAPACK on fp32 data) are 2 % off (seeded fuzz, options 104 / 42).
+static const int CHOL_F64_MAX = 512;
+
+namespace {
+__global__ void chol_widen_kernel(const float* __restrict__ src, long lds_, double* __restrict__ dst, long ldd, int n) {
+  const int r = blockIdx.y;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) dst[(long)r * ldd + c] = (double)src[(long)r * lds_ + c];
+}
+// the factor lives in the row-major lower triangle; everything above the diagonal becomes zero
+__global__ void chol_narrow_lower_kernel(const double* __restrict__ src, long lds_, float* __restrict__ dst, long ldd, int n) {
+  const int r = blockIdx.y;
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x)
+    dst[(long)r * ldd + c] = (c <= r) ? (float)src[(long)r * lds_ + c] : 0.f;
+}
+// last pivot through its absolute value (abs_last_pivot of pmd_chol_inverse): memory row m - 1 holds y = U_11^{-T} c in its first
+// m - 1 entries and C_mm in the last; U_mm = sqrt(|C_mm - y^T y|)
+__global__ void chol_last_pivot_kernel(double* __restrict__ U, long ld, int m, int* __restrict__ info) {
+  __shared__ double red[256];
+  double* row = U + (long)(m - 1) * ld;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < m - 1; i += 256) s += row[i] * row[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int k = 128; k > 0; k >>= 1) {
+    if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double p = row[m - 1] - red[0];
+    if (!(fabs(p) > 0.0)) { if (*info == 0) *info = m; }
+    else row[m - 1] = sqrt(fabs(p));
+  }
+}
+}  // namespace
+
 // In place: C = U_c^T U_c (row-major lower triangle read) -> Et = U_c^{-T} (row-major lower, rest zeroed).
-size_t pmd_chol_inverse_workspace_bytes_impl(int m) { return ((size_t)m + CHOL_NB) * CHOL_NB * sizeof(float) + 8192; }
+size_t pmd_chol_inverse_workspace_bytes_impl(int m) {
+  return ((size_t)m + CHOL_NB) * CHOL_NB * sizeof(float) + (m <= CHOL_F64_MAX ? (size_t)m * m * sizeof(double) + 64 : 0) + 8192;
+}
 
 int pmd_chol_inverse_impl(pmd_ctx* ctx, float* C, int m, long ldc, int abs_last_pivot, int* ok_host, void* ws, size_t ws_bytes) {
   pmd_arena ar(ws, ws_bytes);
@@ -1256,6 +1296,36 @@ int pmd_chol_inverse_impl(pmd_ctx* ctx, float* C, int m, long ldc, int abs_last_
   if (ar.overflow) return pmd_fail(ctx, PMD_ERR_WORKSPACE, "pmd_chol_inverse", "workspace too small");
   *ok_host = 0;
   int hinfo = 0;
+  if (m <= CHOL_F64_MAX && m >= 1 && !getenv("PMD_CHOLESKY")) {
+    pmd_prof_scope prof__(ctx, "cholesky_f64");
+    double* Cd = ar.take_n<double>((size_t)m * m);
+    if (ar.overflow) return pmd_fail(ctx, PMD_ERR_WORKSPACE, "pmd_chol_inverse", "workspace too small");
+    PMD_HIP(ctx, hipMemsetAsync(info, 0, 2 * sizeof(int), ctx->stream));
+    hipLaunchKernelGGL(chol_widen_kernel, dim3((m + 255) / 256, m), dim3(256), 0, ctx->stream, C, ldc, Cd, (long)m, m);
+    PMD_LAUNCH_CHECK(ctx, "chol_widen_kernel");
+    // the row-major lower triangle is the column-major upper one: C = U^T U
+    const int mf = abs_last_pivot ? m - 1 : m;
+    if (mf > 0) PMD_BLAS(ctx, rocsolver_dpotrf(ctx->blas, rocblas_fill_upper, mf, Cd, m, info));
+    if (abs_last_pivot) {
+      if (m > 1)
+        PMD_BLAS(ctx, rocblas_dtrsv(ctx->blas, rocblas_fill_upper, rocblas_operation_transpose, rocblas_diagonal_non_unit, m - 1, Cd, m,
+                                    Cd + (long)(m - 1) * m, 1));
+      hipLaunchKernelGGL(chol_last_pivot_kernel, dim3(1), dim3(256), 0, ctx->stream, Cd, (long)m, m, info + 1);
+      PMD_LAUNCH_CHECK(ctx, "chol_last_pivot_kernel");
+    }
+    int h2[2] = {0, 0};
+    PMD_HIP(ctx, hipMemcpyAsync(h2, info, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    PMD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (h2[0] != 0 || h2[1] != 0) return PMD_OK;   // not positive definite: ok_host stays 0, C is untouched
+    PMD_BLAS(ctx, rocsolver_dtrtri(ctx->blas, rocblas_fill_upper, rocblas_diagonal_non_unit, m, Cd, m, info));
+    PMD_HIP(ctx, hipMemcpyAsync(h2, info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    hipLaunchKernelGGL(chol_narrow_lower_kernel, dim3((m + 255) / 256, m), dim3(256), 0, ctx->stream, Cd, (long)m, C, ldc, m);
+    PMD_LAUNCH_CHECK(ctx, "chol_narrow_lower_kernel");
+    PMD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (h2[0] != 0) return pmd_fail(ctx, PMD_ERR_BLAS, "rocsolver_dtrtri", "singular factor");
+    *ok_host = 1;
+    return PMD_OK;
+  }
   {
     const char* cmode = getenv("PMD_CHOLESKY");
     if (cmode && !strcmp(cmode, "rocsolver") && !abs_last_pivot) {

@@ -1,10 +1,10 @@
 """One draw of the 'wide' fuzz family through the HIP path under its A/B settings (orthogonaliser route, null-direction
 rule) next to the oracle forms: fit to the data, singular values, orthonormality.
-    python scripts/debug_wide.py SEED N_DRAWN CASE"""
+    python scripts/debug_wide.py SEED N_DRAWN CASE [FAMILY]"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tests.test_gpu_fuzz import draw_wide_cases, probe_fit
+from tests.test_gpu_fuzz import draw_wide_cases, draw_option_cases, draw_cases, probe_fit
 import tests.test_gpu_parity as tp
 from tests.util import DeviceSource
 from oracle import pmd_oracle as O
@@ -13,12 +13,15 @@ from localmd_amd import decomposition as Dm
 from localmd_amd._lib import Context
 
 seed, n, case = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
-c = [c for c in draw_wide_cases(n, seed) if c[0] == case][0]
-_, T, d1, d2, b1, b2, frames, kw = c
+family = sys.argv[4] if len(sys.argv) > 4 else "wide"
+c = [c for c in {"wide": draw_wide_cases, "options": draw_option_cases, "base": draw_cases}[family](n, seed) if c[0] == case][0]
+_, T, d1, d2, b1, b2, frames, kw = c[:8]
+extra = c[8] if len(c) > 8 else {"noise": 1.0}
 print(c, flush=True)
 ctx = Context(0)
 Dm.QUIET = True
-mov = tp._movie(T, d1, d2, seed=1000 + case)
+from localmd_amd.synthetic import make_movie
+mov = make_movie(T, d1, d2, seed=1000 + case, noise=extra["noise"])
 order = kw.get("order", "F")
 
 def orc(lapack="double", fp64=False, thr=None):

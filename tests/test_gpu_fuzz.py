@@ -340,6 +340,11 @@ def check_case(fig):
     # reference's own fp32 arithmetic
     e1, e0 = fig["fit"]
     unresolvable = fig.get("gram_cond") is not None and fig["gram_cond"] < 16 * np.finfo(np.float32).eps
+    # the same regime reached through rank_prune (the Gram matrix of the randomly mixed traces): recognised by the
+    # reference's own arithmetic - in BOTH LAPACK precisions - missing the float64 signal singular values by more than 1 %
+    arb_ = fig.get("arbiter", {})
+    if "oracle fp32" in arb_ and "oracle fp32 single-LAPACK" in arb_:
+        unresolvable = unresolvable or min(arb_["oracle fp32"]["s_signal"], arb_["oracle fp32 single-LAPACK"]["s_signal"]) > 1e-2
     if abs(e1 - e0) >= 0.05 * e0 + 1e-6:
         fits = fig.get("fits")
         assert fits is not None, fig["fit"]
