@@ -592,61 +592,153 @@ constexpr int Q2G = 64;    // sweeps per block
 constexpr int Q2V = 32;    // vectors per workgroup
 constexpr int Q2W = Q2G + SB - 1;   // positions per block (127)
 
+// sum over the 8 lanes of a vector's lane group, result in all of them (quad butterflies + the mirror of a half row)
+__device__ __forceinline__ float q2_sum8(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+  return v;
+}
+
+// One reflector of a block: the lane group of a vector holds the reflector's 64-position window in registers (8 positions a
+// lane; logical position u of step count C lives in r[(u - C) & 7], so that sliding the window by one position - the next
+// reflector sits one position lower - moves no register: the slot of the position that leaves takes the one that enters).
+#define Q2_STEP(C)                                                                                                          \
+  {                                                                                                                         \
+    /* operands of this step were requested one step ahead; request the next step's now (row a - 1; row 0 again at the end) */ \
+    const float4 va = nva, vb = nvb;                                                                                        \
+    const float tau = ntau, zin = nzin;                                                                                     \
+    const int an = a > 0 ? a - 1 : 0;                                                                                       \
+    nva = *reinterpret_cast<const float4*>(&vsc[an][8 * part]);                                                             \
+    nvb = *reinterpret_cast<const float4*>(&vsc[an][8 * part + 4]);                                                         \
+    ntau = (an < ns) ? tauc[an] : 0.f;                                                                                      \
+    nzin = zt[v][an > 0 ? an - 1 : 0];       /* the position that enters after step an (used by part 0 only) */             \
+    float d0 = r[(0 - C) & 7] * va.x, d1 = r[(1 - C) & 7] * va.y;                                                            \
+    d0 = fmaf(r[(2 - C) & 7], va.z, d0); d1 = fmaf(r[(3 - C) & 7], va.w, d1);                                                \
+    d0 = fmaf(r[(4 - C) & 7], vb.x, d0); d1 = fmaf(r[(5 - C) & 7], vb.y, d1);                                                \
+    d0 = fmaf(r[(6 - C) & 7], vb.z, d0); d1 = fmaf(r[(7 - C) & 7], vb.w, d1);                                                \
+    const float f = tau * q2_sum8(d0 + d1);                                                                                 \
+    r[(0 - C) & 7] = fmaf(-f, va.x, r[(0 - C) & 7]); r[(1 - C) & 7] = fmaf(-f, va.y, r[(1 - C) & 7]);                        \
+    r[(2 - C) & 7] = fmaf(-f, va.z, r[(2 - C) & 7]); r[(3 - C) & 7] = fmaf(-f, va.w, r[(3 - C) & 7]);                        \
+    r[(4 - C) & 7] = fmaf(-f, vb.x, r[(4 - C) & 7]); r[(5 - C) & 7] = fmaf(-f, vb.y, r[(5 - C) & 7]);                        \
+    r[(6 - C) & 7] = fmaf(-f, vb.z, r[(6 - C) & 7]); r[(7 - C) & 7] = fmaf(-f, vb.w, r[(7 - C) & 7]);                        \
+    if (a > 0) {                                                                                                            \
+      const float out = r[(7 - C) & 7];                                                                                     \
+      float in = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, out), 0x111, 0xF, 0xF, true)); /* row_shr:1 */ \
+      if (part == 7) zt[v][a + SB - 1] = out;                                                                               \
+      r[(7 - C) & 7] = (part == 0) ? zin : in;                                                                              \
+    }                                                                                                                       \
+    --a;                                                                                                                    \
+  }
+
+typedef __attribute__((address_space(3))) void* q2_lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* q2_gbl_ptr_t;
+
 __global__ __launch_bounds__(256) void apply_q2_kernel(float* __restrict__ Z, long ldz, int n, int nvec, const float* __restrict__ V2,
                                                        const float* __restrict__ tau2) {
   __shared__ float zt[Q2V][Q2W + 2];
-  __shared__ float vs[Q2G][SB + 1];
-  __shared__ float taus[Q2G];
-  const int tid = threadIdx.x;
-  const int v = tid >> 3, part = tid & 7;      // vector v of the slab, positions part * 8 .. + 7 of a reflector window
+  __shared__ __attribute__((aligned(16))) float zn[Q2V][SB];            // the 64 positions the next block adds (LDS-DMA target)
+  __shared__ __attribute__((aligned(16))) float vs[2][Q2G][SB];         // reflectors of the current / the next block
+  __shared__ __attribute__((aligned(16))) float taus[2][Q2G];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int v = tid >> 3, part = tid & 7;      // vector v of the slab; positions 8 part .. 8 part + 7 of the reflector window
   const long v0 = (long)blockIdx.x * Q2V;
-  const bool vec_ok = v0 + v < nvec;
   const int n_sweeps = n - 2;
   const int n_groups = (n_sweeps + Q2G - 1) / Q2G;
   for (int S = n_groups - 1; S >= 0; --S) {
     const int s_lo = S * Q2G;
-    const int ns = min(Q2G, n_sweeps - s_lo);
-    const int kmax = (n - s_lo - 1 + SB - 1) / SB;       // tasks of the group's first sweep (the longest)
+    const int ns = min(Q2G, n_sweeps - s_lo);           // sweeps of the group; reflectors beyond them count with tau = 0
+    const int kmax = (n - s_lo - 1 + SB - 1) / SB;      // blocks with p0 = s_lo + 1 + k SB < n
+    // Block k + 1 needs 64 more positions of every vector and its own 64 reflectors: requested as LDS-DMA transfers
+    // (global_load_lds: no staging registers, nothing the compiler can move behind the compute loop) while block k computes.
+    // Addresses are clamped into the arrays; what lies beyond the matrix is masked when it is used.
+    auto prefetch = [&](int k_next, int q0, int buf) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int vv = 8 * wid + j;
+        const long row = (v0 + vv < nvec) ? v0 + vv : v0;
+        __builtin_amdgcn_global_load_lds((q2_gbl_ptr_t)(Z + row * ldz + min(q0 + lane, n - 1)), (q2_lds_ptr_t)&zn[vv][0], 4, 0, 0);
+      }
+      const float* blk = V2 + ((long)k_next * n + s_lo) * SB;      // 64 x 64 floats, contiguous, 256-byte aligned
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int m = 4 * wid + j;                                 // 1 KiB piece m: rows 4 m .. 4 m + 3
+        __builtin_amdgcn_global_load_lds((q2_gbl_ptr_t)(blk + 256 * m + 4 * lane), (q2_lds_ptr_t)(&vs[buf][0][0] + 256 * m), 16, 0, 0);
+      }
+      if (wid == 0)
+        __builtin_amdgcn_global_load_lds((q2_gbl_ptr_t)(tau2 + (long)k_next * n + s_lo + lane), (q2_lds_ptr_t)&taus[buf][0], 4, 0, 0);
+    };
+    {
+      // first block of the group: the leading 63 positions through registers, the rest and the reflectors as for every block
+      const int p0 = s_lo + 1;
+      float ta[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int e = tid + 256 * i, vv = e >> 6, q = e & 63;
+        const bool ok = p0 + q < n && v0 + vv < nvec;
+        ta[i] = Z[(v0 + (ok ? vv : 0)) * ldz + (ok ? p0 + q : 0)];
+      }
+      __syncthreads();
+      prefetch(0, p0 + 63, 0);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int e = tid + 256 * i, vv = e >> 6, q = e & 63;
+        if (q < 63) zt[vv][q] = (p0 + q < n && v0 + vv < nvec) ? ta[i] : 0.f;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the barrier alone does not wait for vector-memory transfers
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int e = tid + 256 * i, vv = e >> 6, q = e & 63;
+        zt[vv][63 + q] = (p0 + 63 + q < n && v0 + vv < nvec) ? zn[vv][q] : 0.f;
+      }
+      __syncthreads();
+    }
     for (int k = 0; k < kmax; ++k) {
       const int p0 = s_lo + 1 + k * SB;
-      if (p0 >= n) break;
-      const int width = min(n - p0, Q2W);
-      __syncthreads();
-      for (int e = tid; e < Q2V * (Q2W + 1); e += 256) {
-        const int vv = e / (Q2W + 1), p = e - vv * (Q2W + 1);
-        zt[vv][p] = (p < width && v0 + vv < nvec) ? Z[(v0 + vv) * ldz + p0 + p] : 0.f;
-      }
-      for (int e = tid; e < Q2G * SB; e += 256) {
-        const int a = e >> 6, i = e & 63;
-        vs[a][i] = (a < ns) ? V2[((long)k * n + s_lo + a) * SB + i] : 0.f;
-      }
-      if (tid < Q2G) taus[tid] = (tid < ns) ? tau2[(long)k * n + s_lo + tid] : 0.f;
-      __syncthreads();
-      for (int a = ns - 1; a >= 0; --a) {
-        const float tau = taus[a];
-        if (tau == 0.f) continue;            // uniform over the workgroup
-        float* zrow = &zt[v][a + part * 8];
-        const float* vr = &vs[a][part * 8];
-        float dot = 0.f;
+      const bool more = k + 1 < kmax;
+      const int cur = k & 1;
+      const float (*vsc)[SB] = vs[cur];
+      const float* tauc = taus[cur];
+      if (more) prefetch(k + 1, p0 + 127, cur ^ 1);
+      float r[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) dot = fmaf(vr[u], zrow[u], dot);
-        dot += __shfl_xor(dot, 1);
-        dot += __shfl_xor(dot, 2);
-        dot += __shfl_xor(dot, 4);
-        dot *= tau;
-#pragma unroll
-        for (int u = 0; u < 8; ++u) zrow[u] -= dot * vr[u];
-        __builtin_amdgcn_wave_barrier();     // keep the LDS accesses of consecutive reflectors in program order
+      for (int u = 0; u < 8; ++u) r[u] = zt[v][Q2G - 1 + 8 * part + u];     // window of the first reflector (a = 63)
+      int a = Q2G - 1;
+      float4 nva = *reinterpret_cast<const float4*>(&vsc[a][8 * part]), nvb = *reinterpret_cast<const float4*>(&vsc[a][8 * part + 4]);
+      float ntau = (a < ns) ? tauc[a] : 0.f, nzin = zt[v][a - 1];
+      for (int it = 0; it < Q2G / 8; ++it) {
+        Q2_STEP(0) Q2_STEP(1) Q2_STEP(2) Q2_STEP(3) Q2_STEP(4) Q2_STEP(5) Q2_STEP(6) Q2_STEP(7)
       }
-      __syncthreads();
-      for (int e = tid; e < Q2V * width; e += 256) {
-        const int vv = e / width, p = e - vv * width;
-        if (v0 + vv < nvec) Z[(v0 + vv) * ldz + p0 + p] = zt[vv][p];
+      // a = 0 was the last reflector (no slide after it): logical position u of step count 63 sits in r[(u - 63) & 7] = r[(u + 1) & 7]
+#pragma unroll
+      for (int u = 0; u < 8; ++u) zt[v][8 * part + u] = r[(u + 1) & 7];
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's transfers for the next block have landed ...
+      __syncthreads();                                   // ... and everybody's; the window is back in the tile
+      // positions 0 .. 63 of the tile are final for this group (all of it after the last block); the rest moves down by 64
+      float keep[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int e = tid + 256 * i, vv = e >> 6, q = e & 63;
+        if (p0 + q < n && v0 + vv < nvec) Z[(v0 + vv) * ldz + p0 + q] = zt[vv][q];
+        keep[i] = zt[vv][64 + q];
+        if (!more && q < 63 && p0 + 64 + q < n && v0 + vv < nvec) Z[(v0 + vv) * ldz + p0 + 64 + q] = keep[i];
+      }
+      if (more) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int e = tid + 256 * i, vv = e >> 6, q = e & 63;
+          if (q < 63) zt[vv][q] = keep[i];
+          zt[vv][63 + q] = (p0 + 127 + q < n && v0 + vv < nvec) ? zn[vv][q] : 0.f;
+        }
+        __syncthreads();
       }
     }
   }
-  (void)vec_ok;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // no transfer may outlive the workgroup's LDS allocation
 }
+#undef Q2_STEP
 
 }  // namespace
 
