@@ -75,12 +75,15 @@ __global__ void panel_copy_out_kernel(const float* __restrict__ Pbuf, long ldp, 
 // Cholesky of the w x w Gram matrix (sum of `slices` partials, symmetrised) in fp64: G = R^T R.  Rout = R (upper, row-major
 // [64][64]), Nout[c'][c] = (R^{-1})[c'][c] (the layout tile_rowmix expects).  A non-positive pivot sets *flag (the panel is
 // rank deficient: the caller falls back to the one-stage reduction).
-__global__ __launch_bounds__(64) void panel_chol_kernel(const double* __restrict__ G, int slices, int w, double* __restrict__ Rout,
-                                                        double* __restrict__ Nout, int* __restrict__ flag) {
+__global__ __launch_bounds__(256) void panel_chol_kernel(const double* __restrict__ G, int slices, int w, double* __restrict__ Rout,
+                                                         double* __restrict__ Nout, int* __restrict__ flag) {
   __shared__ double R[64][65];
   __shared__ double Ri[64][65];
-  const int t = threadIdx.x;
-  for (int i = 0; i < 64; ++i) {
+  __shared__ int bad_s;
+  const int tid = threadIdx.x;
+  const int t = tid & 63, q = tid >> 6;          // column t, quarter q of the rows / of an inner sum
+  if (tid == 0) bad_s = 0;
+  for (int i = q; i < 64; i += 4) {
     double s = 0.0;
     if (i < w && t < w)
       for (int k = 0; k < slices; ++k) s += G[(long)k * 4096 + i * 64 + t] + G[(long)k * 4096 + t * 64 + i];
@@ -90,34 +93,37 @@ __global__ __launch_bounds__(64) void panel_chol_kernel(const double* __restrict
   __syncthreads();
   double dmax = 0.0;
   for (int i = 0; i < w; ++i) dmax = fmax(dmax, R[i][i]);
-  bool bad_any = false;
   for (int k = 0; k < w; ++k) {
     const double piv = R[k][k];
     const bool bad = !(piv > 1e-13 * dmax);
-    bad_any |= bad;
     const double rkk = bad ? 1.0 : sqrt(piv);
     double rkt = 0.0;
     if (t >= k && t < w) rkt = bad ? ((t == k) ? 1.0 : 0.0) : R[k][t] / rkk;
     __syncthreads();
-    if (t >= k && t < w) R[k][t] = rkt;
+    if (q == 0 && t >= k && t < w) R[k][t] = rkt;
+    if (tid == 0 && bad) bad_s = 1;
     __syncthreads();
     if (!bad && t > k && t < w)
-      for (int i = k + 1; i <= t; ++i) R[i][t] -= R[k][i] * rkt;
+      for (int i = k + 1 + q; i <= t; i += 4) R[i][t] -= R[k][i] * rkt;
     __syncthreads();
   }
-  if (t < w) {
-    for (int i = t; i >= 0; --i) {
-      double s = (i == t) ? 1.0 : 0.0;
-      for (int j = i + 1; j <= t; ++j) s -= R[i][j] * Ri[j][t];
-      Ri[i][t] = s / R[i][i];
-    }
+  // R^{-1} (upper): column t by back substitution, the inner sum split over the four threads of the column
+  // (tid = 64 q + t: the four threads of a column sit in four different waves, so the partial sums meet in LDS)
+  __shared__ double part[4][64];
+  for (int i = w - 1; i >= 0; --i) {
+    double s = 0.0;
+    if (t < w && i <= t)
+      for (int j = i + 1 + q; j <= t; j += 4) s += R[i][j] * Ri[j][t];
+    part[q][t] = s;
+    __syncthreads();
+    if (q == 0 && t < w && i <= t) Ri[i][t] = (((i == t) ? 1.0 : 0.0) - (part[0][t] + part[1][t] + part[2][t] + part[3][t])) / R[i][i];
+    __syncthreads();
   }
-  __syncthreads();
-  for (int i = 0; i < 64; ++i) {
+  for (int i = q; i < 64; i += 4) {
     Rout[i * 64 + t] = (i < w && t < w && t >= i) ? R[i][t] : 0.0;
     Nout[i * 64 + t] = (i < w && t < w) ? Ri[i][t] : 0.0;
   }
-  if (t == 0 && bad_any) *flag = 1;
+  if (tid == 0 && bad_s) *flag = 1;
 }
 
 // Householder reconstruction (Ballard, Demmel, Grigori, Jacquelin, Nguyen, Solomonik 2014) of the panel's orthonormal factor.
@@ -291,7 +297,7 @@ int pmd_sy2sb_impl(pmd_ctx* ctx, int n, float* A, long lda, float* tau1, int* fl
     for (int pass = 0; pass < 2; ++pass) {
       const int slices = std::max(1, std::min(GS, m / 256));
       RUN(pmd_launch_tile_gram(ctx, Pbuf, 64 * ldp, ldp, m, 1, slices, gpart));
-      hipLaunchKernelGGL(panel_chol_kernel, dim3(1), dim3(64), 0, st, gpart, slices, w, pass == 0 ? R1 : R2, N1, flag);
+      hipLaunchKernelGGL(panel_chol_kernel, dim3(1), dim3(256), 0, st, gpart, slices, w, pass == 0 ? R1 : R2, N1, flag);
       PMD_LAUNCH_CHECK(ctx, "panel_chol_kernel");
       RUN(pmd_launch_tile_rowmix(ctx, Pbuf, 64 * ldp, ldp, N1, 4096, w, w, Pbuf, 64 * ldp, ldp, m, 1));
     }
