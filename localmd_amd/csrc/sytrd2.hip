@@ -390,7 +390,7 @@ __global__ __launch_bounds__(SW * 256) void sb2st_kernel(float* __restrict__ AB,
   {
     const int k_first = q * h - 2 * s;
     float tp = 0.f;
-    if (s < n - 2 && k_first >= 1) {
+    if (s < n - 2 && k_first >= 1 && s + 1 + (long)(k_first - 1) * SB < n) {   // (a window may start behind the sweep's last task)
       const long idx = (long)(k_first - 1) * n + s;
       if (tt < SB) vprev[team][tt] = V2[idx * SB + tt];
       tp = tau2[idx];
@@ -524,6 +524,181 @@ __global__ __launch_bounds__(SW * 256) void sb2st_kernel(float* __restrict__ AB,
   }
 }
 
+
+// ---- second form: one WAVE per task (lane i = row i of the 64 x 64 blocks).  The off-diagonal block lives in the lane's
+// registers (row access) and in LDS (column access for z = v^T B), the diagonal block in registers only; vectors are
+// broadcast with readlane, reductions run on DPP, nothing inside a step needs a workgroup barrier: one barrier per step keeps
+// the WSW sweeps of a workgroup in lockstep.  Same scheduling as above (task (s, k) at step 2 s + k, workgroup g runs window
+// L - g in launch L).
+constexpr int WSW = 8;         // sweeps (= waves) per workgroup
+
+__device__ __forceinline__ float wave_sum64(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+}
+
+__device__ __forceinline__ float lane_bcast(float v, int l) {   // l: compile-time constant after unrolling
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+
+__global__ __launch_bounds__(WSW * 64) void sb2st_wave_kernel(float* __restrict__ AB, int n, int launch, int h, int g_lo,
+                                                              float* __restrict__ V2, float* __restrict__ tau2) {
+  __shared__ float Bs[WSW][SB][SB + 1];
+  // vectors every lane needs in full are published in LDS and read back four at a time (one broadcast read serves the wave)
+  __shared__ __attribute__((aligned(16))) float vec[WSW][4][SB];     // 0: v_prev, 1: v, 2: z, 3: q
+  const int g = g_lo + blockIdx.x;
+  const int q = launch - g;
+  const int team = threadIdx.x >> 6, i = threadIdx.x & 63;   // lane i = row i of the task's blocks
+  const int s = g * WSW + team;
+  if (q < 0) return;
+  float* vp_s = vec[team][0];
+  float* v_s = vec[team][1];
+  float* z_s = vec[team][2];
+  float* q_s = vec[team][3];
+  // the previous reflector of the sweep (task k - 1 ran in the previous step, possibly in the previous launch)
+  float tauprev = 0.f;
+  {
+    const int k_first = q * h - 2 * s;
+    float vp = 0.f;
+    if (s < n - 2 && k_first >= 1 && s + 1 + (long)(k_first - 1) * SB < n) {   // (a window may start behind the sweep's last task)
+      const long idx = (long)(k_first - 1) * n + s;
+      vp = V2[idx * SB + i];
+      tauprev = tau2[idx];
+    }
+    vp_s[i] = vp;
+  }
+  for (int t = q * h; t < (q + 1) * h; ++t) {
+    const int k = t - 2 * s;
+    const int r0 = s + 1 + k * SB;
+    const bool exists = s < n - 2 && k >= 0 && r0 < n && !(k == 0 && n - r0 < 2);
+    if (exists) {
+      const int L = min(SB, n - r0);
+      const bool row = i < L;
+      // ---- load: row i of Bm = B(r_k, r_{k-1}) (k >= 1) and of D = B(r_k, r_k).  32-bit element offsets from AB (the band has
+      // n * 128 elements); rows / columns beyond the matrix read element 0 of their stream and are masked afterwards; every
+      // load is issued before the first use.
+      float b[SB], d[SB];
+      {
+        // Bm(i, j) = AB[(c0 + j) * LDB + SB + i - j] = AB[ob + j * (LDB - 1)]
+        const unsigned ob = (unsigned)((r0 - SB) * LDB + SB + (row ? i : 0));
+        // D(i, j), j <= i: AB[(r0 + j) * LDB + i - j] = AB[ol + j * (LDB - 1)];  j > i: AB[(r0 + i) * LDB + j - i] = AB[ou + j]
+        const unsigned ol = (unsigned)(r0 * LDB + (row ? i : 0)), ou = (unsigned)((r0 + (row ? i : 0)) * LDB - (row ? i : 0));
+        if (k >= 1) {
+#pragma unroll
+          for (int j = 0; j < SB; ++j) b[j] = AB[ob + (unsigned)(j * (LDB - 1))];
+        }
+#pragma unroll
+        for (int j = 0; j < SB; ++j) {
+          const unsigned jj = (j < L) ? (unsigned)j : 0u;
+          d[j] = AB[((int)jj <= (row ? i : 0)) ? ol + jj * (unsigned)(LDB - 1) : ou + jj];
+        }
+#pragma unroll
+        for (int j = 0; j < SB; ++j) {
+          b[j] = (row && k >= 1) ? b[j] : 0.f;
+          d[j] = (row && j < L) ? d[j] : 0.f;
+        }
+      }
+      float x;   // the column the new reflector annihilates: B(r_0, s) for k = 0, column 0 of Bm (after (a)) otherwise
+      if (k >= 1) {
+        // ---- (a) Bm <- Bm (I - tau_prev v_prev v_prev^T)
+        float part = 0.f;
+#pragma unroll
+        for (int j = 0; j < SB; j += 4) {
+          const float4 w = *reinterpret_cast<const float4*>(vp_s + j);
+          part = fmaf(b[j], w.x, part); part = fmaf(b[j + 1], w.y, part); part = fmaf(b[j + 2], w.z, part); part = fmaf(b[j + 3], w.w, part);
+        }
+        const float f = tauprev * part;
+#pragma unroll
+        for (int j = 0; j < SB; j += 4) {
+          const float4 w = *reinterpret_cast<const float4*>(vp_s + j);
+          b[j] = fmaf(-f, w.x, b[j]); b[j + 1] = fmaf(-f, w.y, b[j + 1]); b[j + 2] = fmaf(-f, w.z, b[j + 2]); b[j + 3] = fmaf(-f, w.w, b[j + 3]);
+        }
+#pragma unroll
+        for (int j = 0; j < SB; ++j) Bs[team][i][j] = b[j];
+        x = b[0];
+      } else {
+        x = AB[(unsigned)(s * LDB + 1 + (row ? i : 0))];
+        x = row ? x : 0.f;
+      }
+      // ---- (b) reflector from x (rows 0 .. L - 1)
+      const float xn2 = wave_sum64((i >= 1 && row) ? x * x : 0.f);
+      const float alpha = lane_bcast(x, 0);
+      float tau = 0.f, beta = alpha, scale = 0.f;
+      if (L >= 2 && xn2 > 0.f) {
+        beta = -copysignf(sqrtf(alpha * alpha + xn2), alpha);
+        tau = (beta - alpha) / beta;
+        scale = 1.f / (alpha - beta);
+      }
+      const float v = row ? ((i == 0) ? 1.f : x * scale) : 0.f;
+      v_s[i] = v;
+      // ---- (c) rest of Bm from the left: z[j] = sum_i v[i] Bm[i][j] (lane j walks column j in LDS), Bm -= tau v z^T
+      if (k >= 1 && tau != 0.f) {
+        float z = 0.f;
+#pragma unroll
+        for (int r = 0; r < SB; r += 4) {
+          const float4 w = *reinterpret_cast<const float4*>(v_s + r);
+          z = fmaf(w.x, Bs[team][r][i], z); z = fmaf(w.y, Bs[team][r + 1][i], z); z = fmaf(w.z, Bs[team][r + 2][i], z); z = fmaf(w.w, Bs[team][r + 3][i], z);
+        }
+        z_s[i] = z;
+        const float f = tau * v;
+#pragma unroll
+        for (int j = 0; j < SB; j += 4) {
+          const float4 w = *reinterpret_cast<const float4*>(z_s + j);
+          if (j > 0) b[j] = fmaf(-f, w.x, b[j]);
+          b[j + 1] = fmaf(-f, w.y, b[j + 1]); b[j + 2] = fmaf(-f, w.z, b[j + 2]); b[j + 3] = fmaf(-f, w.w, b[j + 3]);
+        }
+      }
+      // ---- (d) D <- H D H:  p = tau D v, alpha2 = -tau p^T v / 2, qv = p + alpha2 v, D -= v qv^T + qv v^T
+      if (tau != 0.f) {
+        float p = 0.f;
+#pragma unroll
+        for (int j = 0; j < SB; j += 4) {
+          const float4 w = *reinterpret_cast<const float4*>(v_s + j);
+          p = fmaf(d[j], w.x, p); p = fmaf(d[j + 1], w.y, p); p = fmaf(d[j + 2], w.z, p); p = fmaf(d[j + 3], w.w, p);
+        }
+        p *= tau;
+        const float pv = wave_sum64(p * v);
+        const float qv = fmaf(-0.5f * tau * pv, v, p);
+        q_s[i] = qv;
+        const unsigned ol = (unsigned)(r0 * LDB + i);
+#pragma unroll
+        for (int j = 0; j < SB; j += 4) {
+          const float4 wq = *reinterpret_cast<const float4*>(q_s + j);
+          const float4 wv = *reinterpret_cast<const float4*>(v_s + j);
+          const float e0 = d[j] - v * wq.x - qv * wv.x, e1 = d[j + 1] - v * wq.y - qv * wv.y;
+          const float e2 = d[j + 2] - v * wq.z - qv * wv.z, e3 = d[j + 3] - v * wq.w - qv * wv.w;
+          if (row && j <= i) AB[ol + (unsigned)(j * (LDB - 1))] = e0;
+          if (row && j + 1 <= i) AB[ol + (unsigned)((j + 1) * (LDB - 1))] = e1;
+          if (row && j + 2 <= i) AB[ol + (unsigned)((j + 2) * (LDB - 1))] = e2;
+          if (row && j + 3 <= i) AB[ol + (unsigned)((j + 3) * (LDB - 1))] = e3;
+        }
+      }
+      // ---- store Bm / the eliminated column, the reflector
+      if (k >= 1) {
+        if (L >= 2) b[0] = (i == 0) ? beta : 0.f;
+        const unsigned ob = (unsigned)((r0 - SB) * LDB + SB + i);
+        if (row) {
+#pragma unroll
+          for (int j = 0; j < SB; ++j) AB[ob + (unsigned)(j * (LDB - 1))] = b[j];
+        }
+      } else if (row) {
+        AB[(unsigned)(s * LDB + 1 + i)] = (i == 0) ? beta : 0.f;
+      }
+      const long idx = (long)k * n + s;
+      V2[idx * SB + i] = v;
+      if (i == 0) tau2[idx] = tau;
+      vp_s[i] = v;
+      tauprev = tau;
+    }
+    __syncthreads();    // the sweeps of the workgroup advance in lockstep: what this step wrote, the next one reads
+  }
+}
+
 }  // namespace
 
 size_t pmd_sb2st_workspace_bytes_impl(int n) {
@@ -548,11 +723,15 @@ int pmd_sb2st_impl(pmd_ctx* ctx, int n, const float* A, long lda, float* d, floa
   PMD_HIP(ctx, hipMemsetAsync(tau2, 0, K * n * sizeof(float), st));
   PMD_HIP(ctx, hipMemsetAsync(V2, 0, K * n * SB * sizeof(float), st));
   if (n > 2) {
-    static int h_env = 0;
-    if (!h_env) { const char* e_ = getenv("PMD_SB2ST_H"); h_env = e_ ? std::max(1, atoi(e_)) : 8; }
-    const int h = h_env;
     const int n_sweeps = n - 2;
-    const int n_wg = (n_sweeps + SW - 1) / SW;
+    static int team_form = -1;   // PMD_SB2ST=team: the first form (256-thread teams, four sweeps per workgroup)
+    if (team_form < 0) { const char* e_ = getenv("PMD_SB2ST"); team_form = (e_ && !strcmp(e_, "team")) ? 1 : 0; }
+    // steps per launch: measured at n = 10^4 - wave form 373 / 393 / 450 ms for h = 2 / 4 / 8, team form 667 ms at h = 8
+    static int h_env = 0;
+    if (!h_env) { const char* e_ = getenv("PMD_SB2ST_H"); h_env = e_ ? std::max(1, atoi(e_)) : (team_form ? 8 : 2); }
+    const int h = h_env;
+    const int SWX = team_form ? SW : WSW;
+    const int n_wg = (n_sweeps + SWX - 1) / SWX;
     auto tasks_of = [&](int s) { return (n - s - 1 + SB - 1) / SB; };   // K_s
     // last step of the whole reduction, windows per workgroup
     long t_max = 0;
@@ -564,15 +743,18 @@ int pmd_sb2st_impl(pmd_ctx* ctx, int n, const float* A, long lda, float* d, floa
       // [2 g SW, 2 (g SW + SW - 1) + K_{g SW} - 1]
       long g_lo = std::max<long>(0, L - Q + 1), g_hi = std::min<long>(n_wg - 1, L);
       while (g_lo <= g_hi) {   // drop workgroups whose window lies before / behind their steps
-        const long q = L - g_lo, t_first = 2L * g_lo * SW, t_last = 2L * (g_lo * SW + SW - 1) + tasks_of((int)(g_lo * SW)) - 1;
+        const long q = L - g_lo, t_first = 2L * g_lo * SWX, t_last = 2L * (g_lo * SWX + SWX - 1) + tasks_of((int)(g_lo * SWX)) - 1;
         if ((q + 1) * h - 1 < t_first || q * h > t_last) ++g_lo; else break;
       }
       while (g_hi >= g_lo) {
-        const long q = L - g_hi, t_first = 2L * g_hi * SW, t_last = 2L * (g_hi * SW + SW - 1) + tasks_of((int)(g_hi * SW)) - 1;
+        const long q = L - g_hi, t_first = 2L * g_hi * SWX, t_last = 2L * (g_hi * SWX + SWX - 1) + tasks_of((int)(g_hi * SWX)) - 1;
         if ((q + 1) * h - 1 < t_first || q * h > t_last) --g_hi; else break;
       }
       if (g_lo > g_hi) continue;
-      hipLaunchKernelGGL(sb2st_kernel, dim3((unsigned)(g_hi - g_lo + 1)), dim3(SW * 256), 0, st, AB, n, (int)L, h, (int)g_lo, V2, tau2);
+      if (team_form)
+        hipLaunchKernelGGL(sb2st_kernel, dim3((unsigned)(g_hi - g_lo + 1)), dim3(SW * 256), 0, st, AB, n, (int)L, h, (int)g_lo, V2, tau2);
+      else
+        hipLaunchKernelGGL(sb2st_wave_kernel, dim3((unsigned)(g_hi - g_lo + 1)), dim3(WSW * 64), 0, st, AB, n, (int)L, h, (int)g_lo, V2, tau2);
     }
     PMD_LAUNCH_CHECK(ctx, "sb2st_kernel");
   }
