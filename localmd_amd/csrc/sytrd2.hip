@@ -546,6 +546,17 @@ __device__ __forceinline__ float lane_bcast(float v, int l) {   // l: compile-ti
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
 
+// The band is addressed through a raw buffer resource: an access of a lane that has no element (rows beyond the block, the
+// upper triangle of the diagonal block) gets an offset beyond the buffer - the hardware returns 0 for such a load and drops
+// such a store - instead of an exec-mask region per access (the first form spent a third of its instructions on those).
+constexpr unsigned BAND_OOB = 0x10000000u;     // element offset beyond any band (1 GiB in bytes; a band has n * 128 elements)
+__device__ __forceinline__ float band_ld(__amdgpu_buffer_rsrc_t r, unsigned elem) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)(elem * 4u), 0, 0));
+}
+__device__ __forceinline__ void band_st(__amdgpu_buffer_rsrc_t r, unsigned elem, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)(elem * 4u), 0, 0);
+}
+
 __global__ __launch_bounds__(WSW * 64) void sb2st_wave_kernel(float* __restrict__ AB, int n, int launch, int h, int g_lo,
                                                               float* __restrict__ V2, float* __restrict__ tau2) {
   __shared__ float Bs[WSW][SB][SB + 1];
@@ -556,6 +567,7 @@ __global__ __launch_bounds__(WSW * 64) void sb2st_wave_kernel(float* __restrict_
   const int team = threadIdx.x >> 6, i = threadIdx.x & 63;   // lane i = row i of the task's blocks
   const int s = g * WSW + team;
   if (q < 0) return;
+  const __amdgpu_buffer_rsrc_t band = __builtin_amdgcn_make_buffer_rsrc(AB, 0, n * LDB * 4, 0x00020000);
   float* vp_s = vec[team][0];
   float* v_s = vec[team][1];
   float* z_s = vec[team][2];
@@ -579,30 +591,22 @@ __global__ __launch_bounds__(WSW * 64) void sb2st_wave_kernel(float* __restrict_
     if (exists) {
       const int L = min(SB, n - r0);
       const bool row = i < L;
-      // ---- load: row i of Bm = B(r_k, r_{k-1}) (k >= 1) and of D = B(r_k, r_k).  32-bit element offsets from AB (the band has
-      // n * 128 elements); rows / columns beyond the matrix read element 0 of their stream and are masked afterwards; every
-      // load is issued before the first use.
+      // ---- load: row i of Bm = B(r_k, r_{k-1}) (k >= 1) and of D = B(r_k, r_k); every load is issued before the first use
       float b[SB], d[SB];
-      {
-        // Bm(i, j) = AB[(c0 + j) * LDB + SB + i - j] = AB[ob + j * (LDB - 1)]
-        const unsigned ob = (unsigned)((r0 - SB) * LDB + SB + (row ? i : 0));
-        // D(i, j), j <= i: AB[(r0 + j) * LDB + i - j] = AB[ol + j * (LDB - 1)];  j > i: AB[(r0 + i) * LDB + j - i] = AB[ou + j]
-        const unsigned ol = (unsigned)(r0 * LDB + (row ? i : 0)), ou = (unsigned)((r0 + (row ? i : 0)) * LDB - (row ? i : 0));
-        if (k >= 1) {
+      // Bm(i, j) = AB[(c0 + j) * LDB + SB + i - j] = AB[ob + j * (LDB - 1)]
+      const unsigned ob = row ? (unsigned)((r0 - SB) * LDB + SB + i) : BAND_OOB;
+      // D(i, j), j <= i: AB[(r0 + j) * LDB + i - j] = AB[ol + j * (LDB - 1)];  j > i: AB[(r0 + i) * LDB + j - i] = AB[ou + j]
+      const unsigned ol = row ? (unsigned)(r0 * LDB + i) : BAND_OOB, ou = row ? (unsigned)((r0 + i) * LDB - i) : BAND_OOB;
+      if (k >= 1) {
 #pragma unroll
-          for (int j = 0; j < SB; ++j) b[j] = AB[ob + (unsigned)(j * (LDB - 1))];
-        }
+        for (int j = 0; j < SB; ++j) b[j] = band_ld(band, ob + (unsigned)(j * (LDB - 1)));
+      } else {
 #pragma unroll
-        for (int j = 0; j < SB; ++j) {
-          const unsigned jj = (j < L) ? (unsigned)j : 0u;
-          d[j] = AB[((int)jj <= (row ? i : 0)) ? ol + jj * (unsigned)(LDB - 1) : ou + jj];
-        }
-#pragma unroll
-        for (int j = 0; j < SB; ++j) {
-          b[j] = (row && k >= 1) ? b[j] : 0.f;
-          d[j] = (row && j < L) ? d[j] : 0.f;
-        }
+        for (int j = 0; j < SB; ++j) b[j] = 0.f;
       }
+#pragma unroll
+      for (int j = 0; j < SB; ++j)
+        d[j] = band_ld(band, (j < L) ? ((j <= i) ? ol + (unsigned)(j * (LDB - 1)) : ou + (unsigned)j) : BAND_OOB);
       float x;   // the column the new reflector annihilates: B(r_0, s) for k = 0, column 0 of Bm (after (a)) otherwise
       if (k >= 1) {
         // ---- (a) Bm <- Bm (I - tau_prev v_prev v_prev^T)
@@ -622,8 +626,7 @@ __global__ __launch_bounds__(WSW * 64) void sb2st_wave_kernel(float* __restrict_
         for (int j = 0; j < SB; ++j) Bs[team][i][j] = b[j];
         x = b[0];
       } else {
-        x = AB[(unsigned)(s * LDB + 1 + (row ? i : 0))];
-        x = row ? x : 0.f;
+        x = band_ld(band, row ? (unsigned)(s * LDB + 1 + i) : BAND_OOB);
       }
       // ---- (b) reflector from x (rows 0 .. L - 1)
       const float xn2 = wave_sum64((i >= 1 && row) ? x * x : 0.f);
@@ -665,29 +668,23 @@ __global__ __launch_bounds__(WSW * 64) void sb2st_wave_kernel(float* __restrict_
         const float pv = wave_sum64(p * v);
         const float qv = fmaf(-0.5f * tau * pv, v, p);
         q_s[i] = qv;
-        const unsigned ol = (unsigned)(r0 * LDB + i);
 #pragma unroll
         for (int j = 0; j < SB; j += 4) {
           const float4 wq = *reinterpret_cast<const float4*>(q_s + j);
           const float4 wv = *reinterpret_cast<const float4*>(v_s + j);
-          const float e0 = d[j] - v * wq.x - qv * wv.x, e1 = d[j + 1] - v * wq.y - qv * wv.y;
-          const float e2 = d[j + 2] - v * wq.z - qv * wv.z, e3 = d[j + 3] - v * wq.w - qv * wv.w;
-          if (row && j <= i) AB[ol + (unsigned)(j * (LDB - 1))] = e0;
-          if (row && j + 1 <= i) AB[ol + (unsigned)((j + 1) * (LDB - 1))] = e1;
-          if (row && j + 2 <= i) AB[ol + (unsigned)((j + 2) * (LDB - 1))] = e2;
-          if (row && j + 3 <= i) AB[ol + (unsigned)((j + 3) * (LDB - 1))] = e3;
+          band_st(band, (j <= i) ? ol + (unsigned)(j * (LDB - 1)) : BAND_OOB, d[j] - v * wq.x - qv * wv.x);
+          band_st(band, (j + 1 <= i) ? ol + (unsigned)((j + 1) * (LDB - 1)) : BAND_OOB, d[j + 1] - v * wq.y - qv * wv.y);
+          band_st(band, (j + 2 <= i) ? ol + (unsigned)((j + 2) * (LDB - 1)) : BAND_OOB, d[j + 2] - v * wq.z - qv * wv.z);
+          band_st(band, (j + 3 <= i) ? ol + (unsigned)((j + 3) * (LDB - 1)) : BAND_OOB, d[j + 3] - v * wq.w - qv * wv.w);
         }
       }
       // ---- store Bm / the eliminated column, the reflector
       if (k >= 1) {
         if (L >= 2) b[0] = (i == 0) ? beta : 0.f;
-        const unsigned ob = (unsigned)((r0 - SB) * LDB + SB + i);
-        if (row) {
 #pragma unroll
-          for (int j = 0; j < SB; ++j) AB[ob + (unsigned)(j * (LDB - 1))] = b[j];
-        }
-      } else if (row) {
-        AB[(unsigned)(s * LDB + 1 + i)] = (i == 0) ? beta : 0.f;
+        for (int j = 0; j < SB; ++j) band_st(band, ob + (unsigned)(j * (LDB - 1)), b[j]);
+      } else {
+        band_st(band, row ? (unsigned)(s * LDB + 1 + i) : BAND_OOB, (i == 0) ? beta : 0.f);
       }
       const long idx = (long)k * n + s;
       V2[idx * SB + i] = v;
