@@ -564,7 +564,9 @@ __global__ __launch_bounds__(WSW * 64) void sb2st_wave_kernel(float* __restrict_
   __shared__ __attribute__((aligned(16))) float vec[WSW][4][SB];     // 0: v_prev, 1: v, 2: z, 3: q
   const int g = g_lo + blockIdx.x;
   const int q = launch - g;
-  const int team = threadIdx.x >> 6, i = threadIdx.x & 63;   // lane i = row i of the task's blocks
+  // (readfirstlane: the wave index is uniform, but only this tells the compiler - without it every per-task quantity lives in
+  // vector registers and every "uniform" branch below becomes an exec-mask region)
+  const int team = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), i = threadIdx.x & 63;   // lane i = row i of the task's blocks
   const int s = g * WSW + team;
   if (q < 0) return;
   const __amdgpu_buffer_rsrc_t band = __builtin_amdgcn_make_buffer_rsrc(AB, 0, n * LDB * 4, 0x00020000);
@@ -582,6 +584,7 @@ __global__ __launch_bounds__(WSW * 64) void sb2st_wave_kernel(float* __restrict_
       vp = V2[idx * SB + i];
       tauprev = tau2[idx];
     }
+    tauprev = lane_bcast(tauprev, 0);
     vp_s[i] = vp;
   }
   for (int t = q * h; t < (q + 1) * h; ++t) {
@@ -631,12 +634,13 @@ __global__ __launch_bounds__(WSW * 64) void sb2st_wave_kernel(float* __restrict_
       // ---- (b) reflector from x (rows 0 .. L - 1)
       const float xn2 = wave_sum64((i >= 1 && row) ? x * x : 0.f);
       const float alpha = lane_bcast(x, 0);
-      float tau = 0.f, beta = alpha, scale = 0.f;
+      float tau_ = 0.f, beta_ = alpha, scale_ = 0.f;
       if (L >= 2 && xn2 > 0.f) {
-        beta = -copysignf(sqrtf(alpha * alpha + xn2), alpha);
-        tau = (beta - alpha) / beta;
-        scale = 1.f / (alpha - beta);
+        beta_ = -copysignf(sqrtf(alpha * alpha + xn2), alpha);
+        tau_ = (beta_ - alpha) / beta_;
+        scale_ = 1.f / (alpha - beta_);
       }
+      const float tau = lane_bcast(tau_, 0), beta = lane_bcast(beta_, 0), scale = lane_bcast(scale_, 0);   // uniform, and known to be
       const float v = row ? ((i == 0) ? 1.f : x * scale) : 0.f;
       v_s[i] = v;
       // ---- (c) rest of Bm from the left: z[j] = sum_i v[i] Bm[i][j] (lane j walks column j in LDS), Bm -= tau v z^T
@@ -672,10 +676,11 @@ __global__ __launch_bounds__(WSW * 64) void sb2st_wave_kernel(float* __restrict_
         for (int j = 0; j < SB; j += 4) {
           const float4 wq = *reinterpret_cast<const float4*>(q_s + j);
           const float4 wv = *reinterpret_cast<const float4*>(v_s + j);
-          band_st(band, (j <= i) ? ol + (unsigned)(j * (LDB - 1)) : BAND_OOB, d[j] - v * wq.x - qv * wv.x);
-          band_st(band, (j + 1 <= i) ? ol + (unsigned)((j + 1) * (LDB - 1)) : BAND_OOB, d[j + 1] - v * wq.y - qv * wv.y);
-          band_st(band, (j + 2 <= i) ? ol + (unsigned)((j + 2) * (LDB - 1)) : BAND_OOB, d[j + 2] - v * wq.z - qv * wv.z);
-          band_st(band, (j + 3 <= i) ? ol + (unsigned)((j + 3) * (LDB - 1)) : BAND_OOB, d[j + 3] - v * wq.w - qv * wv.w);
+          // lower triangle only (j <= i): the sign of i - j, spread over the word, pushes the other lanes out of range
+          band_st(band, ol + (unsigned)(j * (LDB - 1)) + ((unsigned)((i - j) >> 31) & BAND_OOB), d[j] - v * wq.x - qv * wv.x);
+          band_st(band, ol + (unsigned)((j + 1) * (LDB - 1)) + ((unsigned)((i - j - 1) >> 31) & BAND_OOB), d[j + 1] - v * wq.y - qv * wv.y);
+          band_st(band, ol + (unsigned)((j + 2) * (LDB - 1)) + ((unsigned)((i - j - 2) >> 31) & BAND_OOB), d[j + 2] - v * wq.z - qv * wv.z);
+          band_st(band, ol + (unsigned)((j + 3) * (LDB - 1)) + ((unsigned)((i - j - 3) >> 31) & BAND_OOB), d[j + 3] - v * wq.w - qv * wv.w);
         }
       }
       // ---- store Bm / the eliminated column, the reflector
