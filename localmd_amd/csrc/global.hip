@@ -759,7 +759,7 @@ __global__ __launch_bounds__(256) void gram_apply_mfma_kernel(const float* __res
   const int a = blockIdx.y;
   const int ra = ranks[a];
   if (ra == 0) return;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (uniform, and known to be)
   const int n16 = lane & 15, kk = lane >> 4;
   const int x0 = blockIdx.x * 256 + wave * 64 + 4 * n16;
   const long xc = (x0 + 3 < ldm) ? x0 : 0;  // idle lanes read valid columns; their results are not stored

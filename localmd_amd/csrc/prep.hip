@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void standardize_transpose_kernel(const float*
   __shared__ float tile[64][65];
   const long c0 = (long)blockIdx.x * 64;
   const int f0 = blockIdx.y * 64;
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int tx = threadIdx.x & 63, ty = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (uniform, and known to be)
   const long c = c0 + tx;
   const float mu = (c < D) ? mean[c] : 0.f;
   const float sg = (c < D) ? stdv[c] : 1.f;

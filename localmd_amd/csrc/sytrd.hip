@@ -181,7 +181,7 @@ __global__ __launch_bounds__(320) void sytrd_advance_kernel(float* __restrict__ 
   __shared__ float s_y[4][APOS + 1], s_u[4][APOS + 1];
   __shared__ float s_red[8];
   __shared__ float s_sp[2];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform, and known to be)
   const int jp = j - 1;
   const int ip = jp - j0;  // earlier panel columns seen by column jp
   int part = wave, slot = lane, r = j + blockIdx.x * APOS + lane;
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(512, CWT == 1024 ? 2 : 4) void sytrd_symv_kernel(co
   __shared__ float s_col[NPG][NRG - 1][64][4];
   __shared__ float s_red[8];
   __shared__ float s_sc[4];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform, and known to be)
   const int wc = wave % NPG, rh = wave / NPG;  // position group and row group of this wave
   const int cs = j + 1;
   const float* xr = A + (long)j * ld;
@@ -707,7 +707,7 @@ __global__ __launch_bounds__(256) void sytrd_rank2k_kernel(float* __restrict__ A
                                                            const float* __restrict__ W, long ldw) {
   const int I = blockIdx.y, J = blockIdx.x;
   if (J < I) return;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (uniform, and known to be)
   const int n16 = lane & 15, kk = lane >> 4;
   const int c0 = ts + 64 * I + 16 * wave, r0 = ts + 64 * J;
   if (c0 >= n) return;

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256 * KS * NS) void tile_atx_kernel(const float* __
   constexpr int TRASH = NBUF * DPAD * LSTR + (KS - 1) * 2048;  // 16-byte slot nobody reads
 
   const int tile = pmd_xcd_tile();
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform, and known to be)
   const int mt = wid & 3, ks = (NS == 1) ? (wid >> 2) : 0, nh = (NS == 1) ? 0 : (wid >> 2);
   const int n16 = lane & 15, kk = lane >> 4;
   const int kz = blockIdx.z;           // grid-level K split (d > DPAD)
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void tile_atx_dma_kernel(const float* __restri
   constexpr int NSLOT = (NINS + 3) / 4;    // pieces per wave
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tile = pmd_xcd_tile();
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform, and known to be)
   const int n16 = lane & 15, kk = lane >> 4;
   const int dloc = min(d, DPAD);
   const int c_begin = blockIdx.y * chunks_per_slice;
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256) void tile_xbt_kernel(const float* __restrict__
                                                        float* __restrict__ S, long s_tile_stride, long s_slice_stride,
                                                        int s_ld, int n_groups_total, int groups_per_slice) {
   const int tile = pmd_xcd_tile();
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (uniform, and known to be)
   const int n16 = lane & 15, kk = lane >> 4;
   const int m0 = (blockIdx.z * 4 + wid) * MPW;  // first M tile of this wave
   const int g_begin = blockIdx.y * groups_per_slice;
@@ -564,7 +564,7 @@ __global__ __launch_bounds__(256) void tile_gram_mfma_kernel(const float* __rest
                                                              int len, int chunk_per_slice, double* __restrict__ G,
                                                              long g_tile_stride) {
   const int tile = blockIdx.x, slice = blockIdx.y;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (uniform, and known to be)
   const int m16 = lane & 15, kq = lane >> 4;
   const float* in = In + (long)tile * tile_stride + (long)m16 * ld + 4 * kq;
   const int x_begin = slice * chunk_per_slice;
@@ -754,7 +754,7 @@ __global__ __launch_bounds__(256) void tile_rowmix_mfma_kernel(const float* __re
                                                                float* __restrict__ Out, long out_tile_stride,
                                                                long ld_out, int len) {
   const int tile = blockIdx.y;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (uniform, and known to be)
   const int n16 = lane & 15, kq = lane >> 4;
   const double* nsrc = N + (long)tile * n_tile_stride;
   double a[16];
