@@ -67,7 +67,15 @@ def cpu_baseline(cfg, movie_dev, seed):
     kw = dict(max_components=cfg["max_components"], rng=philox.PhiloxSource(seed), sim_iters=n_sim)
     full = d1 * d2 * T <= 256 * 256 * 2000
     crop = (d1, d2) if full else (min(d1, 128), min(d2, 128))
-    sub = movie_dev[:, :crop[0], :crop[1]].cpu().numpy()
+    if hasattr(movie_dev, "cpu"):
+        sub = movie_dev[:, :crop[0], :crop[1]].cpu().numpy()
+    else:
+        # one-shot / slab sources are not subscriptable (and a one-shot source has been consumed): the window is generated
+        # again from the same formula, identical to the same pixels of the movie that was decomposed
+        import torch
+        from localmd_amd.synthetic import make_movie_torch
+
+        sub = make_movie_torch(T, d1, d2, torch.device("cuda", 0), seed=0, rows=(0, crop[0]))[:, :, :crop[1]].cpu().numpy()
     np.random.seed(0)
     t0 = time.perf_counter()
     res = O.localmd_decomposition(sub, (b, b), cfg["frames"], **kw)
@@ -184,8 +192,13 @@ def main():
     for _ in range(args.warmup):
         one_step()
     barrier()
-    ctx.profile_enable(True)
+    # The timed steps run WITHOUT the library's HIP-event profiling (round-2 verdict: measurement overhead does not
+    # belong in the headline number); the per-kernel times and both roofline objects come from the one extra,
+    # untimed, instrumented step below.  Exception: a one-shot workload has only one step, which is then both.
     one_shot_diag = None
+    prof = None
+    if cfg.get("one_shot"):
+        ctx.profile_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         if cfg.get("one_shot"):
@@ -194,17 +207,22 @@ def main():
             one_step()
     barrier()
     elapsed = time.perf_counter() - t0
-    prof = ctx.profile_summary()
-    ctx.profile_enable(False)
+    if cfg.get("one_shot"):
+        prof = ctx.profile_summary()
+        ctx.profile_enable(False)
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    # one extra, untimed, instrumented run for the per-phase breakdown and the tile statistics
+    # one extra, untimed, instrumented run: per-phase breakdown, tile statistics, per-kernel HIP-event times
     diag = one_shot_diag
     if diag is None:
+        ctx.profile_enable(True)
         _, diag = one_step(diag=True)
+        barrier()
+        prof = ctx.profile_summary()
+        ctx.profile_enable(False)
     # PCIe-inclusive figure (never `value`): the same decomposition handed a HOST array (pageable NumPy memory), i.e.
     # including the staging through pinned buffers and the H2D transfer (localmd_amd/decomposition.py: _Movie._stream_in)
     host_rate = None
@@ -320,7 +338,9 @@ def main():
         "frames_per_s_from_host_array": host_rate,
         "phases_ms": {k: 1e3 * v for k, v in diag["timings"].items()},
         "hbm_peak_allocated_gb": torch.cuda.max_memory_allocated(device) / 2 ** 30,
-        "kernel_ms_per_step": {k: v[0] / args.steps for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
+        "kernel_ms_per_step": {k: v[0] for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
+        "kernel_ms_source": "HIP events on the launch stream during one untimed instrumented step" if not cfg.get("one_shot")
+                            else "HIP events on the launch stream during the (only) timed step",
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, movie, seed)

@@ -79,6 +79,7 @@ int pmd_background_rsvd(pmd_ctx* ctx, const float* xs, long D, int n, long ld, i
 size_t pmd_bg_project_workspace_bytes(long D, int T);
 int pmd_bg_project(pmd_ctx* ctx, const float* xs, long D, int T, long ld, const float* basis, int K, float* pj_out,
                    long ldp, void* ws, size_t ws_bytes);
+/* pmd_bg_filter: xf_out == xs (in place) is allowed - the pass is element-wise per (pixel, frame). */
 int pmd_bg_filter(pmd_ctx* ctx, const float* xs, float* xf_out, long D, int nf, long ld, const float* basis, int K,
                   const float* pj, long ldp);
 /* pixel_weighting (decomposition.py:717-718) */

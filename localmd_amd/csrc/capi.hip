@@ -464,7 +464,11 @@ int pmdk_sytrd2(pmd_ctx* ctx, int n, float* A, long lda, float* tau1, float* d, 
   CTX_CHECK(ctx);
   const size_t b1 = pmd_sy2sb_workspace_bytes_impl(n), b2 = pmd_sb2st_workspace_bytes_impl(n);
   void *w1 = nullptr, *w2 = nullptr;
-  if (hipMalloc(&w1, b1) != hipSuccess || hipMalloc(&w2, b2) != hipSuccess) return pmd_fail(ctx, PMD_ERR_HIP, "pmdk_sytrd2", "hipMalloc");
+  if (hipMalloc(&w1, b1) != hipSuccess) return pmd_fail(ctx, PMD_ERR_HIP, "pmdk_sytrd2", "hipMalloc");
+  if (hipMalloc(&w2, b2) != hipSuccess) {
+    (void)hipFree(w1);
+    return pmd_fail(ctx, PMD_ERR_HIP, "pmdk_sytrd2", "hipMalloc");
+  }
   int rc = pmd_sy2sb_impl(ctx, n, A, lda, tau1, flag_host, w1, b1);
   float *V2 = nullptr, *tau2 = nullptr;
   if (rc == PMD_OK) rc = pmd_sb2st_impl(ctx, n, A, lda, d, e, &V2, &tau2, w2, b2);

@@ -139,7 +139,9 @@ __global__ __launch_bounds__(256) void neighbour_image_kernel(const double* __re
         if (kind == 0) val = cross / sqrt(ssp * ssq);
         else val = (cross / (n - 1.0)) / sqrt((ssp / n) * (ssq / n));
         total += val;
-        best = (val > best) ? val : best;   // max(cov, net_corr): a NaN never replaces the running maximum
+        // Python's max(cov, net_corr) (diagnostic_plots.py:150-151) keeps net_corr only if `net_corr > cov` is true: a NaN value
+        // (zero-variance neighbour) REPLACES the running maximum, and the next neighbour then replaces the NaN, without the 0 floor
+        best = (best > val) ? best : val;
         ++count;
       }
       ++k;

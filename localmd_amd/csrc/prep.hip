@@ -251,7 +251,9 @@ int pmd_launch_standardize_transpose(pmd_ctx* ctx, const float* movie, long D, c
 // frame column: its K projections stay in registers while the workgroup walks 64 pixel rows, so the
 // pass is one read + one write of the movie (the basis row is a wave-uniform broadcast load).
 template <int KMAX>
-__global__ __launch_bounds__(256) void filter_kernel(const float* __restrict__ in, float* __restrict__ out, long D,
+// `in` and `out` may be the SAME array (the single-copy memory plan filters in place): neither is __restrict__, every live
+// thread reads and writes only its own column, and the clamped loads of the padding threads are discarded.
+__global__ __launch_bounds__(256) void filter_kernel(const float* in, float* out, long D,
                                                      int nf, long ld, const float* __restrict__ basis, int K,
                                                      const float* __restrict__ pj, long ldp) {
   const long f = (long)blockIdx.x * 256 + threadIdx.x;

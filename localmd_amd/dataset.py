@@ -93,8 +93,12 @@ class ArrayDataset(lazy_data_loader):
 
 class TiffArray(lazy_data_loader):
     """Multipage-TIFF reader (reference: dataset.py:131-181).  Uses ``tifffile`` when it is
-    importable, otherwise the built-in reader for uncompressed, strip-based grayscale TIFF /
-    BigTIFF (localmd_amd/_minitiff.py)."""
+    importable, otherwise the built-in reader (localmd_amd/_minitiff.py: grayscale TIFF / BigTIFF, strips or tiles,
+    uncompressed / LZW / deflate / PackBits, predictor 2, ImageJ single-IFD hyperstacks; anything else raises
+    NotImplementedError naming the unsupported tag).  Every read opens its own file handle, so the ingestion
+    path may call ``__getitem__`` from several threads (``thread_safe``)."""
+
+    thread_safe = True
 
     def __init__(self, filename):
         self.filename = filename

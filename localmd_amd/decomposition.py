@@ -38,6 +38,10 @@ from .parallel import Dist, tile_partition
 
 STREAM_PRUNE = 5
 QUIET = False
+# Cholesky route, kept null direction: the rotated-in constant vector is carried next to the joint SVD only when its pivot is
+# below this fraction of the mean diagonal of C (pure rounding: 1e-10 ... 1e-8 measured); a resolved direction goes through
+# the joint SVD like any other.
+NULL_PIVOT_REL = 1e-6
 
 
 def display(msg):
@@ -124,8 +128,16 @@ class _Movie:
         on_gpu = self.ctx.device.type == "cuda"
         frame_bytes = 4 * self.D
         step = max(1, min(int(frame_batch_size), self.STAGE_BYTES // max(frame_bytes, 1), self.T))
-        n_threads = int(num_workers) if num_workers and num_workers > 0 else min(32, os.cpu_count() or 1)
         is_array = isinstance(dataset_obj, np.ndarray)
+        # num_workers = 0 is in-process, single-threaded loading in the reference (pmd_loader.py:161-168; workers > 0 are
+        # separate processes with a dataset copy each).  A user's lazy_data_loader may share a file handle or a decoder
+        # that is not re-entrant, so its __getitem__ is called from ONE reader thread unless num_workers > 0 is passed,
+        # which then promises a thread-safe __getitem__ (as does a true `thread_safe` attribute of the loader, which the
+        # built-in TiffArray has).  Slicing a NumPy array is thread-safe: many copy threads.
+        if num_workers and num_workers > 0:
+            n_threads = int(num_workers)
+        else:
+            n_threads = min(32, os.cpu_count() or 1) if (is_array or getattr(dataset_obj, "thread_safe", False)) else 1
         full_rows = (i_lo == 0 and i_hi == self.d1)
         key = (step, self.D, on_gpu)
         if key not in _Movie._stage_cache:
@@ -851,6 +863,7 @@ def localmd_decomposition(
         P_dev = Et_dev = None
         chol_ok = False
         null_tail = False
+        null_info = {}              # kept null direction of the Cholesky route: pivot level, coupling left out (diagnostics)
         shard = False               # rows of right / GM / Z / R split over the ranks (Cholesky route only)
         row_lo, row_hi = 0, Rc
         Z = W1 = None
@@ -982,6 +995,7 @@ def localmd_decomposition(
                     ctx.call("pmd_gram_mtgm", ptr(right[row_lo:]), nrow, m_eff, ld_right, ptr(GM[row_lo:]), m_cols,
                              ptr(Et_dev), m_cols, ptr(Mt_buf), Mt_buf.numel() * 4)
                 dist.all_reduce(Et_dev)
+                tr_c_dev = Et_dev.diagonal()[:m_eff].sum() if abs_last else None   # scale of C for the null-pivot test below
                 # The Cholesky step (C -> Et) is a chain of small latency-bound launches; the V projection
                 # Z = (UW)^T Y and the large product M^T Z do not depend on it.  Those are enqueued on the main
                 # stream first, then the Cholesky step runs on a second stream next to them.
@@ -1017,6 +1031,13 @@ def localmd_decomposition(
                     rp = m_eff
                     m_used = m_eff
                     if abs_last:
+                        # Is the last pivot really at rounding level?  (with a large mean / noise ratio the
+                        # fp32 centring leaves the constant vector a small but resolved direction; splitting it off would
+                        # then drop real signal.)  Et[m-1][m-1] = 1 / sqrt(|pivot|); compared with the mean diagonal of C.
+                        piv = 1.0 / max(float(Et_dev[m_eff - 1, m_eff - 1].item()) ** 2, 1e-300)
+                        null_pivot_rel = piv / max(float(tr_c_dev.item()) / m_eff, 1e-300)
+                        null_info["pivot_rel"] = null_pivot_rel
+                    if abs_last and null_pivot_rel <= NULL_PIVOT_REL:
                         # The last row of Et is the kept numerically null direction (scale 1 / sqrt(|last pivot|), as the
                         # reference's 1 / sqrt(|lambda|), decomposition.py:984-996).  Its coupling to the other directions is
                         # rounding noise, so it is carried as one extra component next to the SVD of the leading
@@ -1109,10 +1130,15 @@ def localmd_decomposition(
                 # the joint SVD of the reference would deflate this row against the other right vectors: do the same
                 # (two passes of classical Gram-Schmidt against the orthonormal rows of Vt), so that Vt stays orthonormal
                 coef = torch.empty((nk,), dtype=torch.float32, device=ctx.device)
-                for _ in range(2):
+                for gs_pass in range(2):
                     ctx.call("pmd_gemm", 0, 0, nk, 1, T, 1.0, ptr(Vt_out), T, ptr(v_null), 1, 0.0, ptr(coef), 1)
+                    if gs_pass == 0 and return_diagnostics:
+                        coef_norm = coef.norm()
                     ctx.call("pmd_gemm", 0, 0, 1, T, nk, -1.0, ptr(coef), nk, ptr(Vt_out), T, 1.0, ptr(v_null), T)
                 s_null = v_null.norm()
+                if return_diagnostics:
+                    # what the split-off leaves out of R diag(s) Vt: p_null (coef^T Vt), relative to the null row itself
+                    null_info["coupling_rel"] = float((coef_norm / torch.clamp(s_null, min=1e-30)).item())
                 s_out[nk:nk + 1] = s_null
                 v_null.div_(torch.where(s_null == 0, torch.ones_like(s_null), s_null))
             # R = right X1 in row blocks; s, Vt and every finished block go to the host on a side stream
@@ -1232,6 +1258,7 @@ def localmd_decomposition(
             "max_components": r, "rank_before": R, "rank_after": rp + (1 if null_tail else 0), "timings": timings,
             "orthogonalizer": ("cholesky" if (use_right and chol_ok) else "eigh"),
             "crop": crop, "dpad": dpad, "v_proj": Vp.cpu().numpy(), "eig_order": min(rp, T), "col_sigma": col_sigma, "n_tile_cols": Rt,
+            "null_direction": dict(null_info, split_off=bool(null_tail)),
         }
         return final_movie, diag
     finally:

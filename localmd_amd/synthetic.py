@@ -29,7 +29,33 @@ def _sources(d1, d2, T, rng, density=2.0 / 400.0):
     return ci, cj, peak, traces
 
 
-def make_movie(T, d1, d2, seed=0, noise=1.0, dtype=np.float32):
+def _ladder_sources(d1, d2, T, n, seed, top=57.0, ratio=0.93):
+    """n bright, spatially separated sources whose singular values form a geometric ladder (ratio between neighbours):
+    footprints of sigma 3 px on a jittered grid, zero-mean spike traces scaled to unit RMS, peaks top * ratio^k.  Gives the
+    decomposition of a synthetic movie well-separated leading components (parity fixtures: SVD vectors are only
+    comparable component by component when their singular values are separated)."""
+    rng = np.random.Generator(np.random.PCG64(1000003 * (seed + 1) + n))
+    g2 = int(math.ceil(math.sqrt(n * d2 / float(d1))))
+    g1 = int(math.ceil(n / float(g2)))
+    cells = rng.permutation(g1 * g2)[:n]
+    ci = ((cells // g2) + 0.5 + rng.uniform(-0.2, 0.2, n)) * (d1 / float(g1))
+    cj = ((cells % g2) + 0.5 + rng.uniform(-0.2, 0.2, n)) * (d2 / float(g2))
+    spikes = (rng.random((n, T)) < 0.02).astype(np.float64)
+    decay = math.exp(-1.0 / 20.0)
+    traces = np.empty((n, T))
+    acc = np.zeros(n)
+    for t in range(T):
+        acc = acc * decay + spikes[:, t]
+        traces[:, t] = acc
+    traces -= traces.mean(axis=1, keepdims=True)
+    traces /= np.sqrt((traces ** 2).mean(axis=1, keepdims=True))
+    peak = top * ratio ** np.arange(n)
+    return ci, cj, peak, traces.astype(np.float32)
+
+
+def make_movie(T, d1, d2, seed=0, noise=1.0, dtype=np.float32, ladder=0, ladder_top=57.0, ladder_ratio=0.93):
+    """ladder = n > 0 adds n bright sources with a geometric ladder of singular values (see _ladder_sources); the rest of
+    the movie (sources, background, noise draws) is unchanged by it."""
     rng = np.random.Generator(np.random.PCG64(seed))
     ci, cj, peak, traces = _sources(d1, d2, T, rng)
     ii = np.arange(d1, dtype=np.float32)[:, None]
@@ -44,6 +70,13 @@ def make_movie(T, d1, d2, seed=0, noise=1.0, dtype=np.float32):
     movie += slow[:, None, None] * ramp[None]
     movie += 100.0
     movie += noise * rng.standard_normal((T, d1, d2), dtype=np.float32)
+    if ladder > 0:
+        li, lj, lpeak, ltr = _ladder_sources(d1, d2, T, int(ladder), seed, ladder_top, ladder_ratio)
+        lfoot = np.empty((len(li), d1, d2), dtype=np.float32)
+        for n in range(len(li)):
+            lfoot[n] = lpeak[n] * np.exp(-((ii - li[n]) ** 2 + (jj - lj[n]) ** 2) / (2 * 3.0 ** 2))
+        lfoot[lfoot < 1e-3 * lpeak[:, None, None]] = 0
+        movie += np.tensordot(ltr.T, lfoot, axes=(1, 0))
     return movie.astype(dtype)
 
 

@@ -277,3 +277,130 @@ def run_config(ctx, name, arbiter=False, single=False, out=print, movie_seed=0, 
             if k != "arbiter fp64":
                 compare(k, v, v.diag["tile_ranks"], oracle_cols(v), "arbiter fp64", arb)
     return {"hip": (pmd, diag), "results": results, "measures": measures, "probes": prb, "movie": mov, "rank_mismatch": mism}
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Committed referee fixtures (tests/golden/make_parity_fixtures.py): the oracle runs ONCE in the build container with
+# the host Philox source; the GPU box compares the HIP path with the stored vectors without running the oracle.
+# The device generator restates the same counter-based streams (rng.hip; equal up to the rounding of logf / sincosf),
+# so the same seed gives the same Gaussian test matrices to ~1 ulp.
+# ------------------------------------------------------------------------------------------------------------
+N_PIX_SAMPLE = 2048
+N_STABLE_COLS = 64
+N_PROBES = 2000
+
+
+def fixture_from_result(res, shape, seed=0):
+    """Arrays of one referee result (OracleResult) that the fixture keeps: everything small in full, the large factors on
+    the compared components / a fixed sample of pixels, columns and probes."""
+    import hashlib
+
+    T, d1, d2 = shape
+    rng = np.random.default_rng(seed)
+    u = res.u.tocsr()
+    u.sort_indices()
+    s = np.asarray(res.s, np.float64)
+    gaps = rel_gaps(s)
+    sig = np.nonzero((gaps > GAP) & (s > 5e-2 * s[0]))[0]
+    pix = np.sort(rng.choice(d1 * d2, size=min(N_PIX_SAMPLE, d1 * d2), replace=False))
+    ur = np.asarray(u[pix] @ np.asarray(res.r[:, sig], np.float64))
+    passed, gap = oracle_cols(res)
+    ntc = len(passed)
+    stable = np.nonzero(passed & (gap > GAP))[0]
+    cols = np.sort(rng.choice(stable, size=min(N_STABLE_COLS, len(stable)), replace=False)) if len(stable) else stable
+    uc = u.tocsc()
+    col_data = [np.asarray(uc.data[uc.indptr[c]:uc.indptr[c + 1]], np.float64) for c in cols]
+    col_rows = [np.asarray(uc.indices[uc.indptr[c]:uc.indptr[c + 1]], np.int32) for c in cols]
+    pi, pt = rng.integers(0, d1 * d2, N_PROBES), rng.integers(0, T, N_PROBES)
+    rec = np.einsum("pk,k,kp->p", np.asarray(u[pi] @ res.r), res.s, res.v[:, pt])
+    return {
+        "tile_ranks": np.asarray(res.diag["tile_ranks"], np.int32), "thresholds": np.asarray(res.diag["thresholds"], np.float64),
+        "rank_before": np.int64(res.diag["rank_before"]), "max_components": np.int64(res.diag["max_components"]),
+        "U_shape": np.asarray(u.shape, np.int64), "U_indptr": np.asarray(u.indptr, np.int32), "U_nnz": np.int64(u.nnz),
+        "U_indices_sha256": np.frombuffer(hashlib.sha256(np.ascontiguousarray(u.indices, np.int32).tobytes()).digest(), np.uint8),
+        "s": np.asarray(res.s, np.float32), "signal": sig.astype(np.int32), "Vt_signal": np.asarray(res.v[sig], np.float32),
+        "pix_sample": pix.astype(np.int32), "UR_signal_sample": ur.astype(np.float32),
+        "col_passed": passed, "col_gap": gap.astype(np.float32), "stable_cols": cols.astype(np.int32),
+        "stable_col_rows": np.concatenate(col_rows) if col_rows else np.zeros(0, np.int32),
+        "stable_col_data": np.concatenate(col_data) if col_data else np.zeros(0),
+        "stable_col_ptr": np.concatenate([[0], np.cumsum([len(c) for c in col_data])]).astype(np.int64),
+        "R_stable_signal": np.asarray(res.r[np.ix_(cols, sig)], np.float32), "R_max_abs": np.float32(np.abs(res.r[:ntc]).max()),
+        "probe_pix": pi.astype(np.int32), "probe_frame": pt.astype(np.int32), "probe_rec": rec.astype(np.float32),
+        "mean_sample": np.asarray(res.mean_img, np.float32).reshape(-1)[pix], "std_sample": np.asarray(res.std_img, np.float32).reshape(-1)[pix],
+    }
+
+
+def measure_fixture(pmd, diag, fx):
+    """The HIP result against one referee of a committed fixture (dict of the arrays above).  Returns plain numbers."""
+    import hashlib
+
+    out = {}
+    u = pmd.u.tocsr()
+    u.sort_indices()
+    out["ranks_equal"] = bool(np.array_equal(diag["tile_ranks"], fx["tile_ranks"]))
+    out["n_rank_mismatch"] = int(np.sum(np.asarray(diag["tile_ranks"]) != fx["tile_ranks"])) if len(diag["tile_ranks"]) == len(fx["tile_ranks"]) else -1
+    out["shape_equal"] = bool(tuple(u.shape) == tuple(fx["U_shape"]) and len(pmd.s) == len(fx["s"]))
+    out["indptr_equal"] = bool(np.array_equal(u.indptr, fx["U_indptr"]))
+    sha = np.frombuffer(hashlib.sha256(np.ascontiguousarray(u.indices, np.int32).tobytes()).digest(), np.uint8)
+    out["indices_equal"] = bool(u.nnz == int(fx["U_nnz"]) and np.array_equal(sha, fx["U_indices_sha256"]))
+    n = min(len(pmd.s), len(fx["s"]))
+    s_a, s_b = np.asarray(pmd.s[:n], np.float64), np.asarray(fx["s"][:n], np.float64)
+    sig = np.asarray(fx["signal"], np.int64)
+    keep = (sig < n)
+    keep &= rel_gaps(s_a)[np.minimum(sig, n - 1)] > GAP      # separated on the HIP side too
+    out["n_signal"] = int(keep.sum())
+    sg = sig[keep]
+    out["s_rel_signal"] = float((np.abs(s_a[sg] - s_b[sg]) / s_b[sg]).max(initial=0.0))
+    valid = s_b > RESOLVABLE * s_b[0]
+    out["s_rel_resolvable"] = float((np.abs(s_a - s_b) / s_b)[valid].max(initial=0.0))
+    va, vb = np.asarray(pmd.v[sg], np.float64), np.asarray(fx["Vt_signal"][keep], np.float64)
+    sgn = np.where(np.sum(va * vb, axis=1) < 0, -1.0, 1.0)
+    out["vt_row_err"] = np.linalg.norm(va * sgn[:, None] - vb, axis=1) / np.linalg.norm(vb, axis=1)
+    # Frobenius error of the compared block of Vt (the north star's "Vt Frobenius error"), relative
+    out["vt_fro_err"] = float(np.linalg.norm(va * sgn[:, None] - vb) / max(np.linalg.norm(vb), 1e-300))
+    pix = np.asarray(fx["pix_sample"], np.int64)
+    ur_a = np.asarray(u[pix] @ np.asarray(pmd.r[:, sg], np.float64)) * sgn[None, :]
+    ur_b = np.asarray(fx["UR_signal_sample"], np.float64)[:, keep]
+    out["ur_col_err"] = np.linalg.norm(ur_a - ur_b, axis=0) / np.maximum(np.linalg.norm(ur_b, axis=0), 1e-300)
+    if out["indptr_equal"] and out["indices_equal"]:
+        a_passed, a_gap = hip_cols(diag)
+        uc = u.tocsc()
+        errs, r_errs, n_cmp = [0.0], [0.0], 0
+        ptr_ = fx["stable_col_ptr"]
+        for k, c in enumerate(np.asarray(fx["stable_cols"], np.int64)):
+            if not (a_passed[c] and a_gap[c] > GAP):
+                continue
+            da = np.asarray(uc.data[uc.indptr[c]:uc.indptr[c + 1]], np.float64)
+            db = fx["stable_col_data"][ptr_[k]:ptr_[k + 1]]
+            if len(da) != len(db) or not np.array_equal(uc.indices[uc.indptr[c]:uc.indptr[c + 1]], fx["stable_col_rows"][ptr_[k]:ptr_[k + 1]]):
+                errs.append(np.inf)
+                continue
+            cs = -1.0 if float(da @ db) < 0 else 1.0
+            errs.append(float(np.abs(cs * da - db).max()))
+            ra = np.asarray(pmd.r[c, sg], np.float64) * cs * sgn
+            r_errs.append(float(np.abs(ra - np.asarray(fx["R_stable_signal"][k], np.float64)[keep]).max(initial=0.0)))
+            n_cmp += 1
+        out["n_stable_cols_compared"] = n_cmp
+        out["u_data_err_stable"] = float(max(errs))
+        out["u_data_max_abs"] = float(np.abs(fx["stable_col_data"]).max(initial=0.0))
+        out["r_err_stable_signal"] = float(max(r_errs))
+        out["r_max_abs"] = float(fx["R_max_abs"])
+    pi, pt = np.asarray(fx["probe_pix"], np.int64), np.asarray(fx["probe_frame"], np.int64)
+    rec = np.einsum("pk,k,kp->p", np.asarray(u[pi] @ pmd.r), pmd.s, pmd.v[:, pt])
+    out["probes"] = float(np.abs(rec - fx["probe_rec"]).max() / np.abs(fx["probe_rec"]).max())
+    out["mean_rel"] = float(np.abs(np.asarray(pmd.mean_img).reshape(-1)[pix] / fx["mean_sample"] - 1).max())
+    out["std_rel"] = float(np.abs(np.asarray(pmd.var_img).reshape(-1)[pix] / fx["std_sample"] - 1).max())
+    return out
+
+
+def fixture_summary(name, m):
+    ln = [f"[{name}] tile ranks equal {m['ranks_equal']} ({m['n_rank_mismatch']} differ), shapes equal {m['shape_equal']}, U_indptr equal {m['indptr_equal']}, "
+          f"U_indices equal {m['indices_equal']}"]
+    ln.append(f"[{name}] signal components compared: {m['n_signal']}; s rel {m['s_rel_signal']:.2e} (all resolvable: {m['s_rel_resolvable']:.2e}); "
+              f"Vt rows max {m['vt_row_err'].max(initial=0):.2e} median {np.median(m['vt_row_err']) if len(m['vt_row_err']) else 0:.2e}, Frobenius {m['vt_fro_err']:.2e}; "
+              f"(U R) columns (pixel sample) max {m['ur_col_err'].max(initial=0):.2e}")
+    if "u_data_err_stable" in m:
+        ln.append(f"[{name}] U_data on {m['n_stable_cols_compared']} stable columns: {m['u_data_err_stable']:.2e} (max |U_data| {m['u_data_max_abs']:.3f}); "
+                  f"R on those rows x signal columns: {m['r_err_stable_signal']:.2e} (max |R| {m['r_max_abs']:.3f})")
+    ln.append(f"[{name}] reconstruction probes {m['probes']:.2e} of the peak; mean_img rel {m['mean_rel']:.2e}, std_img rel {m['std_rel']:.2e}")
+    return ln

@@ -65,3 +65,25 @@ def test_chunked_streaming_and_inputs(gpu_ctx, monkeypatch):
     np.testing.assert_allclose(got, DO.make_residual_correlation_image(mov, dense, "max"), rtol=1e-3, atol=1e-5)
     with pytest.raises(ValueError):
         DI.make_correlation_image(mov, mode="median", ctx=gpu_ctx)
+
+
+@pytest.mark.parametrize("mode", ["max", "mean"])
+def test_dead_pixels_follow_python_max_semantics(gpu_ctx, mode):
+    """A zero-variance (dead / saturated) pixel makes every correlation with it NaN.  The reference's running maximum is
+    Python's max(cov, net_corr) (diagnostic_plots.py:150-151), which lets a NaN replace the maximum and the next neighbour
+    replace the NaN without the floor at 0: pixels whose LAST neighbour is the dead one come out NaN, others may come out
+    negative.  The kernel reproduces exactly that, NaN positions included."""
+    import warnings
+    from localmd_amd import diagnostic_images as DI
+
+    mov = _movie(T=500, d1=11, d2=12, seed=5).copy()
+    mov[:, 4, 6] = 37.0
+    mov[:, 0, 0] = 5.0
+    mov[:, 10, 11] = 0.0
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        want = DO.make_correlation_image(mov, mode)
+    got = DI.make_correlation_image(mov, mode=mode, ctx=gpu_ctx)
+    assert np.isnan(want).any() and not np.isnan(want).all()
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-6)

@@ -176,8 +176,6 @@ def test_synthetic_slab_source_matches_whole_movie(gpu_ctx):
         assert torch.equal(src.slab(lo, hi), whole[:, lo:hi, :])
 
 
-@pytest.mark.slow
-@pytest.mark.skipif(__import__("os").environ.get("PMD_RUN_SLOW", "") != "1", reason="84 GB movie, ~1 minute: set PMD_RUN_SLOW=1")
 def test_config4_1024x1024x20000_one_gpu_properties(gpu_ctx):
     """BASELINE config 4 at full size on ONE GPU (BASELINE.json quotes it on 8): the single-copy memory plan keeps the
     84 GB movie, its one standardised copy and the order-20 000 global stage inside 288 GB (peak 244 GB measured)."""
@@ -194,8 +192,6 @@ def test_config4_1024x1024x20000_one_gpu_properties(gpu_ctx):
     _check_properties(pmd, diag, noisy, T, d1, d2, block, clean_band=(480, 544))
 
 
-@pytest.mark.slow
-@pytest.mark.skipif(__import__("os").environ.get("PMD_RUN_SLOW", "") != "1", reason="84 GB movie, ~1 minute: set PMD_RUN_SLOW=1")
 def test_config5_2048x2048x5000_one_gpu_properties(gpu_ctx):
     """BASELINE config 5 at full size on ONE GPU: 65 025 tiles of 16 x 16 pixels, > 10^6 tile components.  The movie is handed
     over through a one-shot source so that the decomposition can release the raw copy (peak 202 GB measured); tiles run in

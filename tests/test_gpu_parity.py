@@ -718,6 +718,38 @@ def test_tiff_dataset_end_to_end(gpu_ctx, tmp_path):
     assert a.shape == (420, 40, 30) and a[7].shape == (40, 30)
 
 
+def test_tiff_fixture_from_an_independent_writer_end_to_end(gpu_ctx):
+    """SURVEY 8(f)1 with a file this repository did not write: tests/golden/pillow_u16_movie_deflate.tif (Pillow /
+    libtiff, deflate-compressed, 260 pages; tests/golden/make_tiff_fixtures.py).  Decomposing it through TiffArray
+    gives exactly what the pixel values stored next to it give as an in-memory array, and the oracle agrees on the
+    structure of that result."""
+    import os
+    import localmd_amd
+    from localmd_amd import decomposition as Dm
+
+    Dm.QUIET = True
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    mov = np.load(os.path.join(golden, "tiff_fixture_expected.npz"))["movie"]
+    kw = dict(max_components=5, background_rank=2, seed=3, thresholds=(1.2, 1.9), ctx=gpu_ctx)
+    np.random.seed(5)
+    a, diag = localmd_amd.localmd_decomposition(localmd_amd.TiffArray(os.path.join(golden, "pillow_u16_movie_deflate.tif")),
+                                                (16, 12), 260, frame_batch_size=50, return_diagnostics=True, **kw)
+    np.random.seed(5)
+    b = localmd_amd.localmd_decomposition(mov.astype(np.float32), (16, 12), 260, **kw)
+    np.testing.assert_array_equal(a.u.indices, b.u.indices)
+    np.testing.assert_array_equal(a.u.data, b.u.data)
+    np.testing.assert_array_equal(a.s, b.s)
+    np.testing.assert_array_equal(a.v, b.v)
+    np.testing.assert_array_equal(a.mean_img, b.mean_img)
+    np.random.seed(5)
+    ref = O.localmd_decomposition(mov.astype(np.float32), (16, 12), 260, max_components=5, background_rank=2,
+                                  rng=DeviceSource(gpu_ctx, 3), thresholds=(1.2, 1.9))
+    np.testing.assert_array_equal(diag["tile_ranks"], ref.diag["tile_ranks"])
+    np.testing.assert_array_equal(a.u.indptr, ref.u.indptr)
+    np.testing.assert_array_equal(a.u.indices, ref.u.indices)
+    np.testing.assert_allclose(a.mean_img, ref.mean_img, rtol=1e-5, atol=1e-3)
+
+
 def test_public_svd_helpers_match_oracle():
     """localmd_amd.projected_svd / compute_lowrank_factorized_svd (the reference's two other public entry points,
     decomposition.py:936-1060) on the device against the oracle: both branches of each."""

@@ -238,6 +238,218 @@ def test_tiff_reader_roundtrip(tmp_path, dt):
     np.testing.assert_array_equal(ta[2:5], frames[2:5].astype(np.float32))
 
 
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.mark.parametrize("name,key", [
+    ("pillow_u16_raw.tif", "u16"), ("pillow_u16_lzw.tif", "u16"), ("pillow_u16_deflate.tif", "u16"),
+    ("pillow_u16_packbits.tif", "u16"), ("pillow_u16_lzw_pred.tif", "u16"), ("pillow_u8_raw.tif", "u8"),
+    ("pillow_f32_raw.tif", "f32"), ("pillow_u16_strips_raw.tif", "wide"), ("pillow_u16_strips_lzw.tif", "wide"),
+    ("pillow_u16_movie_deflate.tif", "movie")])
+def test_tiff_fixtures_written_by_pillow(name, key):
+    """files written by an independent encoder (Pillow / libtiff, tests/golden/make_tiff_fixtures.py) -
+    multipage, several strips per page, LZW / deflate / PackBits, horizontal predictor - read pixel-exact through
+    TiffArray (the reference reads them through tifffile, dataset.py:131-181)."""
+    expected = np.load(os.path.join(GOLDEN, "tiff_fixture_expected.npz"))[key]
+    ta = localmd_amd.TiffArray(os.path.join(GOLDEN, name))
+    assert ta.shape == expected.shape and ta.ndim == 3
+    got = ta[list(range(expected.shape[0]))]
+    assert got.dtype == np.float32
+    np.testing.assert_array_equal(got, expected.astype(np.float32))
+    pick = [expected.shape[0] - 1, 0, 2]
+    np.testing.assert_array_equal(ta[pick], expected[pick].astype(np.float32))
+    np.testing.assert_array_equal(ta[1:3, 2:7, 3], expected[1:3, 2:7, 3].astype(np.float32))
+    np.testing.assert_array_equal(ta[-1], expected[-1].astype(np.float32))
+
+
+def _craft_tiff(path, frames, endian="<", tiles=None, big=False, compression=1, imagej=False):
+    """A second, test-local TIFF writer for the layouts Pillow does not produce: big-endian, BigTIFF, tiled pages,
+    deflate-compressed tiles, ImageJ's single-IFD hyperstack."""
+    import struct
+    import zlib
+
+    T, h, w = frames.shape
+    dt = frames.dtype.newbyteorder(endian)
+    kind = {"u": 1, "i": 2, "f": 3}[frames.dtype.kind]
+    ifd_fmt = (endian + "HHQ8s") if big else (endian + "HHI4s")
+    blobs = []          # page payloads, written first
+    with open(path, "wb") as f:
+        f.write(struct.pack(endian + "2sHHHQ", b"II" if endian == "<" else b"MM", 43, 8, 0, 0) if big else
+                struct.pack(endian + "2sHI", b"II" if endian == "<" else b"MM", 42, 0))
+        pages = []
+        for t in range(1 if imagej else T):
+            offs, cnts = [], []
+            if imagej:
+                chunks = [frames.astype(dt).tobytes()]
+            elif tiles:
+                tl, tw = tiles
+                chunks = []
+                for i0 in range(0, h, tl):
+                    for j0 in range(0, w, tw):
+                        tile = np.zeros((tl, tw), dtype=dt)
+                        blk = frames[t, i0:i0 + tl, j0:j0 + tw]
+                        tile[:blk.shape[0], :blk.shape[1]] = blk
+                        chunks.append(tile.tobytes())
+            else:
+                chunks = [frames[t].astype(dt).tobytes()]
+            for c in chunks:
+                if compression == 8:
+                    c = zlib.compress(c)
+                offs.append(f.tell())
+                cnts.append(len(c))
+                f.write(c)
+                if f.tell() % 2:
+                    f.write(b"\0")
+            pages.append((offs, cnts))
+        prev_next_pos = 8 if big else 4
+        for t, (offs, cnts) in enumerate(pages):
+            n_chunks = len(offs)
+            arr_pos = f.tell()
+            off_t = 16 if big else 4
+            f.write(struct.pack(endian + ("Q" if big else "I") * n_chunks, *offs))
+            f.write(struct.pack(endian + ("Q" if big else "I") * n_chunks, *cnts))
+            desc = b"ImageJ=1.53\nimages=%d\nframes=%d\n\0" % (T, T) if imagej else b""
+            desc_pos = f.tell()
+            f.write(desc)
+            if f.tell() % 2:
+                f.write(b"\0")
+            ifd_pos = f.tell()
+            here = f.tell()
+            f.seek(prev_next_pos)
+            f.write(struct.pack(endian + ("Q" if big else "I"), ifd_pos))
+            f.seek(here)
+
+            def val(typ, count, v):
+                size = {3: 2, 4: 4, 16: 8, 2: 1}[typ] * count
+                room = 8 if big else 4
+                if size <= room:
+                    if typ == 2:
+                        return v.ljust(room, b"\0")
+                    return struct.pack(endian + {3: "H", 4: "I", 16: "Q"}[typ] * count, *(v if count > 1 else [v])).ljust(room, b"\0")
+                return struct.pack(endian + ("Q" if big else "I"), v)   # v is then a file offset
+
+            size_t = 8 if big else 4
+            ents = [(256, 4, 1, w), (257, 4, 1, h), (258, 3, 1, 8 * frames.dtype.itemsize), (259, 3, 1, compression),
+                    (262, 3, 1, 1), (277, 3, 1, 1), (339, 3, 1, kind)]
+            one = n_chunks == 1
+            if tiles:
+                ents += [(322, 4, 1, tiles[1]), (323, 4, 1, tiles[0]),
+                         (324, off_t, n_chunks, offs[0] if one else arr_pos),
+                         (325, off_t, n_chunks, cnts[0] if one else arr_pos + n_chunks * size_t)]
+            else:
+                ents += [(273, off_t, n_chunks, offs[0] if one else arr_pos), (278, 4, 1, h),
+                         (279, off_t, n_chunks, cnts[0] if one else arr_pos + n_chunks * size_t)]
+            if imagej:
+                ents.append((270, 2, len(desc), desc_pos))
+            ents.sort()
+            f.write(struct.pack(endian + ("Q" if big else "H"), len(ents)))
+            for tag, typ, count, v in ents:
+                if n_chunks > 1 and tag in (273, 279, 324, 325) or tag == 270:
+                    payload = struct.pack(endian + ("Q" if big else "I"), v).ljust(8 if big else 4, b"\0")
+                else:
+                    payload = val(typ, count, v)
+                f.write(struct.pack(endian + "HH", tag, typ) + struct.pack(endian + ("Q" if big else "I"), count) + payload)
+            prev_next_pos = f.tell()
+            f.write(struct.pack(endian + ("Q" if big else "I"), 0))
+
+
+@pytest.mark.parametrize("kw", [dict(endian=">"), dict(big=True), dict(tiles=(16, 16)), dict(tiles=(16, 32), compression=8),
+                                dict(endian=">", tiles=(16, 16), big=True), dict(imagej=True), dict(compression=8, endian=">")])
+@pytest.mark.parametrize("dt", [np.uint16, np.float32])
+def test_tiff_reader_layouts(tmp_path, kw, dt):
+    rng = np.random.default_rng(5)
+    frames = (rng.random((5, 37, 41)) * 3000).astype(dt)
+    fn = str(tmp_path / "c.tif")
+    _craft_tiff(fn, frames, **kw)
+    ta = localmd_amd.TiffArray(fn)
+    assert ta.shape == frames.shape
+    np.testing.assert_array_equal(ta[[4, 0, 2]], frames[[4, 0, 2]].astype(np.float32))
+
+
+def test_tiff_reader_refuses_what_it_cannot_decode(tmp_path):
+    """Unsupported layouts fail loudly with the tag named (INTEGRATION.md lists them), never with wrong pixels."""
+    import struct
+    from localmd_amd._minitiff import MiniTiff, write_tiff
+
+    frames = np.arange(2 * 6 * 8, dtype=np.uint16).reshape(2, 6, 8)
+    fn = str(tmp_path / "x.tif")
+    write_tiff(fn, frames)
+    raw = bytearray(open(fn, "rb").read())
+
+    def patched(tag, value):
+        out = bytearray(raw)
+        (n,) = struct.unpack("<H", out[8:10])
+        for i in range(n):
+            pos = 10 + 12 * i
+            if struct.unpack("<H", out[pos:pos + 2])[0] == tag:
+                out[pos + 8:pos + 10] = struct.pack("<H", value)
+        path = str(tmp_path / "p{}_{}.tif".format(tag, value))
+        open(path, "wb").write(out)
+        return path
+
+    for tag, value in ((259, 7), (259, 50000), (277, 3), (258, 12)):
+        with pytest.raises(NotImplementedError):
+            MiniTiff(patched(tag, value))
+    with pytest.raises(IndexError):
+        MiniTiff(fn).read([2])
+    with pytest.raises(ValueError):
+        open(str(tmp_path / "n.tif"), "wb").write(b"not a tiff at all")
+        MiniTiff(str(tmp_path / "n.tif"))
+
+
+def test_lazy_loader_is_never_reentered_by_default():
+    """num_workers = 0 means in-process single-threaded loading in the reference (pmd_loader.py:161-168).  A
+    user's loader (shared file handle, non-re-entrant decoder) must be read by one thread at a time unless the caller
+    passes num_workers > 0 or the loader declares thread_safe."""
+    import threading
+    import time as _time
+    import types
+    import torch
+    from localmd_amd.dataset import lazy_data_loader
+    from localmd_amd.decomposition import _Movie
+
+    rng = np.random.default_rng(1)
+    data = rng.random((64, 9, 7)).astype(np.float32)
+
+    class Guarded(lazy_data_loader):
+        def __init__(self):
+            self.inside = 0
+            self.max_inside = 0
+            self.lock = threading.Lock()
+
+        @property
+        def dtype(self):
+            return np.float32
+
+        @property
+        def shape(self):
+            return data.shape
+
+        def _compute_at_indices(self, idx):
+            with self.lock:
+                self.inside += 1
+                self.max_inside = max(self.max_inside, self.inside)
+            _time.sleep(0.002)
+            out = data[idx]
+            with self.lock:
+                self.inside -= 1
+            return out
+
+    fake_ctx = types.SimpleNamespace(device=torch.device("cpu"))
+    src = Guarded()
+    mv = _Movie(fake_ctx, src, 16)
+    np.testing.assert_array_equal(mv.dev.numpy(), data.reshape(64, -1))
+    assert src.max_inside == 1
+    src = Guarded()
+    mv = _Movie(fake_ctx, src, 16, num_workers=4)      # the caller asked for concurrent readers
+    np.testing.assert_array_equal(mv.dev.numpy(), data.reshape(64, -1))
+    assert src.max_inside >= 1
+    src = Guarded()
+    src.thread_safe = True
+    mv = _Movie(fake_ctx, src, 16)
+    np.testing.assert_array_equal(mv.dev.numpy(), data.reshape(64, -1))
+
+
 # ------------------------------------------------------------------ C ABI surface -----------
 def test_library_exports_every_declared_symbol():
     assert os.path.exists(_lib.LIB_PATH), "libpmd_hip.so missing: run localmd_amd/csrc/build.sh"
