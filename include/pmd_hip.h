@@ -19,9 +19,11 @@
  *   pixel-major  X[c][t]            leading dimension ld = pmd_time_ld(T); zero padded
  *   tile pixels  pix[tile][q]       q = il + b1*jl (column-major inside the tile, as the
  *                                   reference's order="F" reshapes), value = FOV pixel c
- *   tile basis   Ut[tile][comp][q]  64 component rows (rows >= rank are zero), row length
- *                                   pmd_tile_dpad(b1*b2)
- *   tile traces  V[tile][comp][t]   64 component rows, leading dimension ldv >= pmd_time_ld(T)
+ *   tile basis   Ut[tile][comp][q]  rp = pmd_tile_rpad(max_components) component rows (64 up to max_components = 54;
+ *                                   rows >= rank are zero), row length pmd_tile_dpad(b1*b2)
+ *   tile traces  V[tile][comp][t]   rp component rows, leading dimension ldv >= pmd_time_ld(T)
+ *   The global-stage entry points (pmd_weight_tiles, pmd_gram_*, pmd_compact_rows, pmd_tiles_project) take blocks of 64
+ *   component rows: an array with rp = 64 v rows is handed to them as v "virtual tiles" per tile, [n*v][64][x], same memory.
  */
 #ifndef PMD_HIP_H
 #define PMD_HIP_H
@@ -51,6 +53,8 @@ int pmd_profile_names(pmd_ctx* ctx, char* buf, int cap);
 
 /* padded sizes every caller needs to allocate buffers */
 int pmd_tile_dpad(int d);       /* padded pixel count of a d-pixel tile (-1: unsupported)   */
+int pmd_tile_rpad(int r);       /* component rows of the per-tile arrays for max_components = r: 64 while r + 10 <= 64
+                                   (the MFMA-tiled main path), round_up(r + 10, 64) beyond (generic-width kernels) */
 long pmd_time_ld(long t);       /* leading dimension of a time-contiguous row of t frames   */
 
 /* Gaussian matrices (replaces jax.random.normal: decomposition.py:62,:127,:870; pmd_loader.py:56).
@@ -71,7 +75,7 @@ int pmd_standardize_transpose(pmd_ctx* ctx, const float* movie, long D, const in
 
 /* A2: background basis = rank-K rSVD of the standardised sample (pmd_loader.py:46-68, :300-314).
  * xs: pixel-major sample with round_up(D,1024) rows allocated (rows >= D zero). basis_out[c][k]. */
-size_t pmd_background_rsvd_workspace_bytes(long D, int n);
+size_t pmd_background_rsvd_workspace_bytes(long D, int n, int K);
 int pmd_background_rsvd(pmd_ctx* ctx, const float* xs, long D, int n, long ld, int K, uint64_t seed, float* basis_out,
                         void* ws, size_t ws_bytes);
 
@@ -95,8 +99,10 @@ int pmd_threshold_sim(pmd_ctx* ctx, int b1, int b2, int t, int iters, uint64_t s
  * evaluation.py:84-222, decomposition.py:501-523).  Omega of tile b is logical array
  * (PMD_STREAM_TILE_OMEGA = 4, omega_index0 + b*omega_index_step).
  * pool_q[P][pool_max]: local pixels of pooling window p (-1 pads); pool_idx[q]: window of pixel q;
- * pool_w[q] = 1/|window|.  n_rows = pixel rows of xf.  Outputs: Ut_out[n][64][dpad], V_out[n][64][ldv] (= sigma*V rows),
- * stats_out[n][64][2], good_out/keep_out[n][64], ranks_out[n], lam_out[n][64] (sigma^2, may be NULL). */
+ * pool_w[q] = 1/|window|.  n_rows = pixel rows of xf.  Outputs, with rp = pmd_tile_rpad(r): Ut_out[n][rp][dpad],
+ * V_out[n][rp][ldv] (= sigma*V rows), stats_out[n][rp][2], good_out/keep_out[n][rp], ranks_out[n], lam_out[n][rp]
+ * (sigma^2, may be NULL).  r is unbounded as in the reference (decomposition.py:643-665); r + 10 > 64 runs the
+ * generic-width kernels of wide.hip. */
 size_t pmd_tiles_workspace_bytes(int n_tiles, int b1, int b2, int P, int r, int a, int t_crop, long ldv, long n_rows);
 int pmd_tiles_decompose(pmd_ctx* ctx, const float* xf, long ldx, long n_rows, int t_crop, const int* tile_pix, int n_tiles, int b1,
                         int b2, const int* pool_q, int pool_max, int P, const int* pool_idx, const float* pool_w, int r,
@@ -105,9 +111,9 @@ int pmd_tiles_decompose(pmd_ctx* ctx, const float* xf, long ldx, long n_rows, in
                         int* good_out, int* keep_out, int* ranks_out, double* lam_out, void* ws, size_t ws_bytes);
 /* The same pipeline in three resumable parts, for the reference's denoiser hooks (arbitrary callables inside
  * single_block_md).  stages is a mask: bit 0 = up to V_ds = U_ds^T X_ds (decomposition.py:279-298); the
- * temporal_denoiser (:300) then acts on V_ds[n][64][ldv] (rows < r, t_crop frames) at byte offset *vds_offset of
+ * temporal_denoiser (:300) then acts on V_ds[n][rp][ldv] (rows < r, t_crop frames) at byte offset *vds_offset of
  * the workspace; bit 1 = basis of its row space and S = X V_b^T (:301-306); the spatial_denoiser (:310) acts on
- * S[n][64][dpad] (row c = component c, tile pixel il + b1*jl) at *s_offset; bit 2 = the rest (:315-328 and the
+ * S[n][rp][dpad] (row c = component c, tile pixel il + b1*jl) at *s_offset; bit 2 = the rest (:315-328 and the
  * keep/discard scan).  The workspace must be left untouched between the calls except for the hook arrays. */
 int pmd_tiles_decompose_staged(pmd_ctx* ctx, const float* xf, long ldx, long n_rows, int t_crop, const int* tile_pix, int n_tiles,
                                int b1, int b2, const int* pool_q, int pool_max, int P, const int* pool_idx,
@@ -221,7 +227,7 @@ int pmd_csr_count(pmd_ctx* ctx, int d1, int d2, int order_f, const int* cover1, 
 int pmd_csr_fill(pmd_ctx* ctx, int d1, int d2, int order_f, int b1, const int* cover1, const int* cover2,
                  const int* orig1, const int* orig2, int n2, const int* ranks, const int* col_off, const float* Ut,
                  int dpad, const float* w, const double* inv_cumw, const float* basis, int K, int Rt, const long* indptr,
-                 double* data, int* indices, int* zero_count);
+                 double* data, int* indices, int* zero_count, int rpad);   /* rpad: component rows of Ut (pmd_tile_rpad) */
 /* row-major C = alpha op(A) op(B) + beta C (the jnp.matmul calls of decomposition.py:873, :982, :993,
  * :1006; pmd_loader.py:412) */
 int pmd_gemm(pmd_ctx* ctx, int transA, int transB, int m, int n, int k, float alpha, const float* A, long lda,

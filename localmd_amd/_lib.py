@@ -26,12 +26,13 @@ SIGNATURES = {
     "pmd_profile_query": (c_i, [c_p, C.c_char_p, C.POINTER(c_d), C.POINTER(c_i)]),
     "pmd_profile_names": (c_i, [c_p, C.c_char_p, c_i]),
     "pmd_tile_dpad": (c_i, [c_i]),
+    "pmd_tile_rpad": (c_i, [c_i]),
     "pmd_time_ld": (c_l, [c_l]),
     "pmd_rng_normal": (c_i, [c_p, c_u64, c_u32, c_u32, c_u32, c_i, c_l, c_i, c_i, c_p, c_l, c_l]),
     "pmd_stats_workspace_bytes": (c_sz, [c_i, c_l, c_i]),
     "pmd_stats": (c_i, [c_p, c_p, c_i, c_l, c_i, c_i, c_p, c_p, c_p, c_sz]),
     "pmd_standardize_transpose": (c_i, [c_p, c_p, c_l, c_p, c_i, c_p, c_p, c_p, c_l]),
-    "pmd_background_rsvd_workspace_bytes": (c_sz, [c_l, c_i]),
+    "pmd_background_rsvd_workspace_bytes": (c_sz, [c_l, c_i, c_i]),
     "pmd_background_rsvd": (c_i, [c_p, c_p, c_l, c_i, c_l, c_i, c_u64, c_p, c_p, c_sz]),
     "pmd_bg_project_workspace_bytes": (c_sz, [c_l, c_i]),
     "pmd_bg_project": (c_i, [c_p, c_p, c_l, c_i, c_l, c_p, c_i, c_p, c_l, c_p, c_sz]),
@@ -85,7 +86,7 @@ SIGNATURES = {
     "pmd_transpose": (c_i, [c_p, c_p, c_l, c_i, c_i, c_p, c_l]),
     "pmd_csr_count": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_p]),
     "pmd_csr_fill": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_i,
-                           c_p, c_p, c_p, c_p]),
+                           c_p, c_p, c_p, c_p, c_i]),
     "pmd_gemm": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_l, c_p, c_l, c_f, c_p, c_l]),
     "pmdk_tile_atx": (c_i, [c_p, c_p, c_l, c_p, c_i, c_l, c_i, c_p, c_l, c_i, c_p, c_l, c_l, c_i, c_i, c_i]),
     "pmdk_tile_xbt": (c_i, [c_p, c_p, c_l, c_p, c_i, c_l, c_i, c_p, c_l, c_l, c_p, c_l, c_l, c_i, c_i, c_i, c_i]),

@@ -5,7 +5,7 @@
 set -e
 cd "$(dirname "$0")"
 OUT=../libpmd_hip.so
-SRCS="capi.hip rng.hip prep.hip tile_gemm.hip small_la.hip pipeline.hip global.hip sytrd.hip sytrd2.hip expand.hip diag.hip comm.hip"
+SRCS="capi.hip rng.hip prep.hip tile_gemm.hip small_la.hip wide.hip pipeline.hip global.hip sytrd.hip sytrd2.hip expand.hip diag.hip comm.hip"
 OBJS=""
 PIDS=()
 NAMES=()

@@ -169,7 +169,7 @@ int pmd_standardize_transpose(pmd_ctx* ctx, const float* movie, long D, const in
   return pmd_launch_standardize_transpose(ctx, movie, D, frames, nf, mean, std, out, ld);
 }
 
-size_t pmd_background_rsvd_workspace_bytes(long D, int n) { return pmd_bg_workspace_bytes_impl(D, n); }
+size_t pmd_background_rsvd_workspace_bytes(long D, int n, int K) { return pmd_bg_workspace_bytes_impl(D, n, K); }
 int pmd_background_rsvd(pmd_ctx* ctx, const float* xs, long D, int n, long ld, int K, uint64_t seed, float* basis_out,
                         void* ws, size_t ws_bytes) {
   CTX_CHECK(ctx);
@@ -355,10 +355,11 @@ int pmd_csr_count(pmd_ctx* ctx, int d1, int d2, int order_f, const int* cover1, 
 int pmd_csr_fill(pmd_ctx* ctx, int d1, int d2, int order_f, int b1, const int* cover1, const int* cover2,
                  const int* orig1, const int* orig2, int n2, const int* ranks, const int* col_off, const float* Ut,
                  int dpad, const float* w, const double* inv_cumw, const float* basis, int K, int Rt, const long* indptr,
-                 double* data, int* indices, int* zero_count) {
+                 double* data, int* indices, int* zero_count, int rpad) {
   CTX_CHECK(ctx);
+  if (rpad < 64 || rpad % 64) return pmd_fail(ctx, PMD_ERR_ARG, "pmd_csr_fill", "rpad must be a positive multiple of 64");
   return pmd_csr_fill_impl(ctx, d1, d2, order_f, b1, cover1, cover2, orig1, orig2, n2, ranks, col_off, Ut, dpad, w,
-                           inv_cumw, basis, K, Rt, indptr, data, indices, zero_count);
+                           inv_cumw, basis, K, Rt, indptr, data, indices, zero_count, rpad);
 }
 size_t pmd_orthogonalize_factored_workspace_bytes(int m) { return pmd_orthogonalize_factored_workspace_bytes_impl(m); }
 int pmd_orthogonalize_factored(pmd_ctx* ctx, const float* M, int Rc, int m, long ldm, const float* GM, long ldgm,

@@ -920,7 +920,7 @@ __global__ void csr_fill_kernel(int d1, int d2, int order_f, int b1, const int* 
                                 const int* __restrict__ col_off, const float* __restrict__ Ut, int dpad,
                                 const float* __restrict__ w, const double* __restrict__ inv_cumw,
                                 const float* __restrict__ basis, int K, int Rt, const long* __restrict__ indptr,
-                                double* __restrict__ data, int* __restrict__ indices, int* __restrict__ zero_count) {
+                                double* __restrict__ data, int* __restrict__ indices, int* __restrict__ zero_count, int rpad) {
   const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= (long)d1 * d2) return;
   int i, j;
@@ -940,7 +940,7 @@ __global__ void csr_fill_kernel(int d1, int d2, int order_f, int b1, const int* 
       const int rk = ranks[tile];
       const int off = col_off[tile];
       for (int c = 0; c < rk; ++c) {
-        const double v = ((double)Ut[(long)tile * 64 * dpad + (long)c * dpad + q] * wq) * inv;
+        const double v = ((double)Ut[(long)tile * rpad * dpad + (long)c * dpad + q] * wq) * inv;
         zeros += (v == 0.0);
         data[pos] = v;
         indices[pos] = off + c;
@@ -971,13 +971,13 @@ int pmd_csr_count_impl(pmd_ctx* ctx, int d1, int d2, int order_f, const int* cov
 int pmd_csr_fill_impl(pmd_ctx* ctx, int d1, int d2, int order_f, int b1, const int* cover1, const int* cover2,
                       const int* orig1, const int* orig2, int n2, const int* ranks, const int* col_off, const float* Ut,
                       int dpad, const float* w, const double* inv_cumw, const float* basis, int K, int Rt,
-                      const long* indptr, double* data, int* indices, int* zero_count) {
+                      const long* indptr, double* data, int* indices, int* zero_count, int rpad) {
   pmd_prof_scope prof__(ctx, "csr_assembly");
   const long D = (long)d1 * d2;
   PMD_HIP(ctx, hipMemsetAsync(zero_count, 0, sizeof(int), ctx->stream));
   hipLaunchKernelGGL(csr_fill_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, ctx->stream, d1, d2, order_f, b1,
                      cover1, cover2, orig1, orig2, n2, ranks, col_off, Ut, dpad, w, inv_cumw, basis, K, Rt, indptr, data,
-                     indices, zero_count);
+                     indices, zero_count, rpad);
   PMD_LAUNCH_CHECK(ctx, "csr_fill_kernel");
   return PMD_OK;
 }

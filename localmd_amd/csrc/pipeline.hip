@@ -43,19 +43,25 @@ static int tile_sketch_basis(pmd_ctx* ctx, const float* Yt, long stride, int ld,
 // per-tile decomposition (decomposition.py:235-330 single_block_md, one window, + :501-523)
 // ------------------------------------------------------------------------------------------
 struct tiles_plan {
-  int nb, l, dpad, Ppad, nref;
+  int nb, l, dpad, Ppad, nref, rp;
   long ld_b;
   float *abar, *omT, *yt, *qt, *bm, *udst, *ut0, *outA, *spart, *sst, *xbar, *g1f;
   double *gpart, *nmat, *lam;
+  void* eig_ws;        // wide path only: workspace of pmd_launch_wide_eig
+  size_t eig_ws_bytes;
   size_t zero_bytes;  // leading part of the workspace that must be zeroed
 };
 
 static const int GRAM_SLICES = 4;
 static const int XBT_SLICES = 4;
 
+// rp = component rows of every per-tile array: 64 on the main path (max_components + 10 <= 64), pmd_tile_rpad(r) beyond
 static int plan_tiles(pmd_arena& ar, tiles_plan& p, int n, int d, int P, int r, int a, int t_crop, long ldv, long n_rows) {
   p.nb = t_crop / a;
   p.l = r + 10;
+  p.rp = pmd_tile_rpad(r);
+  const size_t rp = p.rp, rp2 = rp * rp;
+  const bool wide = p.rp > 64;
   p.dpad = pmd_tile_dpad(d);
   p.Ppad = pmd_tile_dpad(P);
   p.nref = (P < p.l) ? P : p.l;
@@ -63,21 +69,27 @@ static int plan_tiles(pmd_arena& ar, tiles_plan& p, int n, int d, int P, int r, 
   if (p.dpad < 0 || p.Ppad < 0) return PMD_ERR_UNSUPPORTED;
   // arrays with padding that is read before it is written come first (they get zeroed)
   p.abar = ar.take_n<float>((size_t)n * P * p.ld_b);
-  p.omT = ar.take_n<float>((size_t)n * 64 * p.ld_b);
-  p.yt = ar.take_n<float>((size_t)n * 64 * p.Ppad);
-  p.qt = ar.take_n<float>((size_t)n * 64 * p.Ppad);
-  p.udst = ar.take_n<float>((size_t)n * 64 * p.Ppad);
-  p.ut0 = ar.take_n<float>((size_t)n * 64 * p.dpad);
-  p.spart = ar.take_n<float>((size_t)n * XBT_SLICES * 64 * p.dpad);
-  p.sst = ar.take_n<float>((size_t)n * 64 * p.dpad);
+  p.omT = ar.take_n<float>((size_t)n * rp * p.ld_b);
+  p.yt = ar.take_n<float>((size_t)n * rp * p.Ppad);
+  p.qt = ar.take_n<float>((size_t)n * rp * p.Ppad);
+  p.udst = ar.take_n<float>((size_t)n * rp * p.Ppad);
+  p.ut0 = ar.take_n<float>((size_t)n * rp * p.dpad);
+  p.spart = wide ? nullptr : ar.take_n<float>((size_t)n * XBT_SLICES * 64 * p.dpad);   // (the wide path runs S = X V^T in one slice)
+  p.sst = ar.take_n<float>((size_t)n * rp * p.dpad);
   p.zero_bytes = ar.used;
-  p.bm = ar.take_n<float>((size_t)n * 64 * p.ld_b);
+  p.bm = ar.take_n<float>((size_t)n * rp * p.ld_b);
   p.xbar = ar.take_n<float>((size_t)n_rows * p.ld_b);
-  p.g1f = ar.take_n<float>((size_t)n * GRAM_SLICES * 4096);
-  p.outA = ar.take_n<float>((size_t)n * 64 * ldv);
-  p.gpart = ar.take_n<double>((size_t)n * GRAM_SLICES * 4096);
-  p.nmat = ar.take_n<double>((size_t)n * 4096);
-  p.lam = ar.take_n<double>((size_t)n * 64);
+  p.g1f = wide ? nullptr : ar.take_n<float>((size_t)n * GRAM_SLICES * 4096);
+  p.outA = ar.take_n<float>((size_t)n * rp * ldv);
+  p.gpart = ar.take_n<double>((size_t)n * GRAM_SLICES * rp2);
+  p.nmat = ar.take_n<double>((size_t)n * rp2);
+  p.lam = ar.take_n<double>((size_t)n * rp);
+  p.eig_ws = nullptr;
+  p.eig_ws_bytes = 0;
+  if (wide) {
+    p.eig_ws_bytes = pmd_wide_eig_workspace_bytes(p.rp, n);
+    p.eig_ws = ar.take(p.eig_ws_bytes);
+  }
   return PMD_OK;
 }
 
@@ -88,6 +100,73 @@ size_t pmd_tiles_workspace_bytes_impl(int n, int d, int P, int r, int a, int t_c
   return ar.used + 4096;
 }
 
+// Orthonormal basis of the row space of a [comp][x] array by two rounds of Gram matrix -> eigen-whitening (E Lambda^-1/2,
+// null directions zeroed) -> row mixing: the generic-width counterpart of CholeskyQR2 / small_qr.  Any orthonormal basis
+// of the sketch's span serves the rSVD (B = Q^T A, U = Q u are invariant under Q -> Q O).
+static int wide_orthonormalise(pmd_ctx* ctx, const tiles_plan& p, const float* src, long stride, long ld, int len, int n_in, int n_out,
+                               float* dst, int n) {
+  for (int pass = 0; pass < 2; ++pass) {
+    RUN(pmd_launch_wide_gram(ctx, src, stride, ld, len, n, 1, p.rp, p.gpart));
+    RUN(pmd_launch_wide_eig(ctx, p.gpart, 1, p.rp, pass == 0 ? n_in : n_out, 1, 1e-12, p.nmat, p.lam, n, p.eig_ws, p.eig_ws_bytes));
+    RUN(pmd_launch_wide_rowmix(ctx, src, stride, ld, p.nmat, (long)p.rp * p.rp, p.rp, pass == 0 ? n_in : n_out, n_out, dst, stride, ld, len, n));
+    src = dst;
+  }
+  return PMD_OK;
+}
+
+// single_block_md (decomposition.py:235-330) with more than 64 component rows: the same sequence as the main path below,
+// with the contractions in row blocks of 64 and the small dense algebra through wide.hip (eigen-whitening wherever the
+// main path uses Householder QR or Cholesky whitening: only spans matter there, see the comments of the main path).
+static int tiles_decompose_wide(pmd_ctx* ctx, const tiles_plan& p, const float* Xf, long ldx, long n_rows, int t_crop, const int* tile_pix,
+                                int n, int b1, int b2, const int* pool_q, int pool_max, int P, const int* pool_idx, const float* pool_w,
+                                int r, int a, float thr_s, float thr_t, int max_fail, uint64_t seed, uint32_t omega_index0,
+                                uint32_t omega_index_step, float* Ut_out, float* V_out, long ldv, float* stats_out, int* good_out,
+                                int* keep_out, int* ranks_out, double* sing_out, void* ws, int stages) {
+  const int d = b1 * b2, rp = p.rp;
+  const long srd = (long)rp * p.dpad, srP = (long)rp * p.Ppad, srb = (long)rp * p.ld_b, srv = (long)rp * ldv, rp2 = (long)rp * rp;
+  if (stages & 1) {
+    PMD_HIP(ctx, hipMemsetAsync(ws, 0, p.zero_bytes, ctx->stream));
+    PMD_HIP(ctx, hipMemsetAsync(Ut_out, 0, (size_t)n * srd * sizeof(float), ctx->stream));
+    RUN(pmd_launch_tile_pool_bin(ctx, Xf, ldx, n_rows, tile_pix, n, d, pool_q, pool_max, P, a, p.nb, p.xbar, p.abar, p.ld_b, (long)P * p.ld_b));
+    for (int t0 = 0; t0 < n; t0 += 32768) {
+      const int tn = (n - t0 < 32768) ? n - t0 : 32768;
+      RUN(pmd_launch_rng(ctx, seed, PMD_STREAM_TILE_OMEGA, omega_index0 + (uint32_t)t0 * omega_index_step, omega_index_step, tn, p.nb,
+                         p.l, 1, p.omT + (long)t0 * srb, p.ld_b, srb));
+    }
+    RUN(pmd_launch_tile_xbt_rp(ctx, p.abar, p.ld_b, nullptr, 0, P, P, p.omT, srb, p.ld_b, p.yt, srP, 0, p.Ppad, n, p.nb, 1, p.l));
+    RUN(wide_orthonormalise(ctx, p, p.yt, srP, p.Ppad, P, p.l, p.nref, p.qt, n));
+    RUN(pmd_launch_tile_atx_rp(ctx, p.abar, p.ld_b, nullptr, 0, P, P, p.qt, srP, p.Ppad, p.bm, srb, p.ld_b, n, p.nb, 1, p.nref));
+    RUN(pmd_launch_wide_gram(ctx, p.bm, srb, p.ld_b, p.nb, n, 1, rp, p.gpart));
+    RUN(pmd_launch_wide_eig(ctx, p.gpart, 1, rp, p.nref, 0, 0.0, p.nmat, p.lam, n, p.eig_ws, p.eig_ws_bytes));
+    RUN(pmd_launch_wide_rowmix(ctx, p.qt, srP, p.Ppad, p.nmat, rp2, rp, p.nref, r, p.udst, srP, p.Ppad, P, n));
+    RUN(pmd_launch_expand_pooled(ctx, p.udst, srP, p.Ppad, pool_idx, pool_w, d, r, p.ut0, srd, p.dpad, n));
+    ctx->atx_label = "tile_atx_main";
+    RUN(pmd_launch_tile_atx_rp(ctx, Xf, ldx, tile_pix, d, 0, d, p.ut0, srd, p.dpad, p.outA, srv, ldv, n, t_crop, 2, r));
+    ctx->atx_label = nullptr;
+  }
+  if (stages & 2) {
+    RUN(pmd_launch_wide_gram(ctx, p.outA, srv, ldv, t_crop, n, GRAM_SLICES, rp, p.gpart));
+    RUN(pmd_launch_wide_eig(ctx, p.gpart, GRAM_SLICES, rp, r, 1, 1e-10, p.nmat, p.lam, n, p.eig_ws, p.eig_ws_bytes));
+    RUN(pmd_launch_tile_xbt_rp(ctx, Xf, ldx, tile_pix, d, 0, d, p.outA, srv, ldv, p.sst, srd, 0, p.dpad, n, t_crop, 1, r));
+    RUN(pmd_launch_wide_rowmix(ctx, p.sst, srd, p.dpad, p.nmat, rp2, rp, r, r, p.sst, srd, p.dpad, d, n));
+  }
+  if (stages & 4) {
+    RUN(pmd_launch_wide_gram(ctx, p.sst, srd, p.dpad, d, n, 1, rp, p.gpart));
+    RUN(pmd_launch_wide_eig(ctx, p.gpart, 1, rp, r, 1, 1e-10, p.nmat, p.lam, n, p.eig_ws, p.eig_ws_bytes));
+    RUN(pmd_launch_wide_rowmix(ctx, p.sst, srd, p.dpad, p.nmat, rp2, rp, r, r, p.sst, srd, p.dpad, d, n));
+    ctx->atx_label = "tile_atx_main";
+    RUN(pmd_launch_tile_atx_rp(ctx, Xf, ldx, tile_pix, d, 0, d, p.sst, srd, p.dpad, V_out, srv, ldv, n, t_crop, 2, r));
+    ctx->atx_label = nullptr;
+    RUN(pmd_launch_wide_gram(ctx, V_out, srv, ldv, t_crop, n, GRAM_SLICES, rp, p.gpart));
+    RUN(pmd_launch_wide_eig(ctx, p.gpart, GRAM_SLICES, rp, r, 0, 0.0, p.nmat, sing_out ? sing_out : p.lam, n, p.eig_ws, p.eig_ws_bytes));
+    RUN(pmd_launch_wide_rowmix(ctx, p.sst, srd, p.dpad, p.nmat, rp2, rp, r, r, Ut_out, srd, p.dpad, d, n));
+    RUN(pmd_launch_wide_rowmix(ctx, V_out, srv, ldv, p.nmat, rp2, rp, r, r, V_out, srv, ldv, t_crop, n));
+    RUN(pmd_launch_stats_roughness(ctx, Ut_out, srd, p.dpad, b1, b2, V_out, srv, ldv, t_crop, r, stats_out, n, rp));
+    RUN(pmd_launch_decide(ctx, stats_out, r, thr_s, thr_t, max_fail, r, n, good_out, keep_out, ranks_out, rp));
+  }
+  return PMD_OK;
+}
+
 int pmd_tiles_decompose_impl(pmd_ctx* ctx, const float* Xf, long ldx, long n_rows, int t_crop, const int* tile_pix, int n, int b1,
                              int b2, const int* pool_q, int pool_max, int P, const int* pool_idx, const float* pool_w,
                              int r, int a, float thr_s, float thr_t, int max_fail, uint64_t seed, uint32_t omega_index0,
@@ -95,7 +174,7 @@ int pmd_tiles_decompose_impl(pmd_ctx* ctx, const float* Xf, long ldx, long n_row
                              int* good_out, int* keep_out, int* ranks_out, double* sing_out, void* ws, size_t ws_bytes,
                              int stages) {
   const int d = b1 * b2;
-  if (r < 1 || r + 10 > 64) return pmd_fail(ctx, PMD_ERR_UNSUPPORTED, "pmd_tiles_decompose", "max_components must be in [1, 54]");
+  if (r < 1) return pmd_fail(ctx, PMD_ERR_ARG, "pmd_tiles_decompose", "max_components must be >= 1");
   if (a < 1 || t_crop % a != 0 || t_crop / a < 1) return pmd_fail(ctx, PMD_ERR_ARG, "pmd_tiles_decompose", "t_crop must be a positive multiple of temporal_avg_factor");
   if (ldv < pmd_time_ld(t_crop) || ldx < pmd_time_ld(t_crop)) return pmd_fail(ctx, PMD_ERR_ARG, "pmd_tiles_decompose", "leading dimension too small");
   pmd_arena ar(ws, ws_bytes);
@@ -108,6 +187,10 @@ int pmd_tiles_decompose_impl(pmd_ctx* ctx, const float* Xf, long ldx, long n_row
   // that exist; everything downstream then works on that many components
   if (r > p.nb) r = p.nb;
   if (r > p.nref) r = p.nref;
+  if (p.rp > 64)
+    return tiles_decompose_wide(ctx, p, Xf, ldx, n_rows, t_crop, tile_pix, n, b1, b2, pool_q, pool_max, P, pool_idx, pool_w, r, a, thr_s,
+                                thr_t, max_fail, seed, omega_index0, omega_index_step, Ut_out, V_out, ldv, stats_out, good_out, keep_out,
+                                ranks_out, sing_out, ws, stages);
   const long s64d = 64L * p.dpad, s64P = 64L * p.Ppad, s64b = 64L * p.ld_b, s64v = 64L * ldv;
   // PMD_TILE_WHITEN=eig restores the eigenvector form of the two pure orthonormalisation steps (A/B runs)
   static int whiten_mode = -1;
@@ -366,11 +449,11 @@ int pmd_threshold_sim_impl(pmd_ctx* ctx, int b1, int b2, int t, int iters, uint6
 // ------------------------------------------------------------------------------------------
 #define BG_BLK 256
 
-__global__ void sum_gram_blocks_kernel(const double* __restrict__ g, int nblk, double* __restrict__ out) {
+__global__ void sum_gram_blocks_kernel(const double* __restrict__ g, int nblk, double* __restrict__ out, int count = 4096) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 4096) return;
+  if (i >= count) return;
   double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += g[(long)b * 4096 + i];
+  for (int b = 0; b < nblk; ++b) s += g[(long)b * count + i];
   out[i] = s;
 }
 
@@ -420,44 +503,83 @@ __global__ __launch_bounds__(64) void chol_inverse_kernel(const double* __restri
   }
 }
 
-__global__ void unblock_basis_kernel(const float* __restrict__ ubt, long D, int K, float* __restrict__ basis) {
+__global__ void unblock_basis_kernel(const float* __restrict__ ubt, long D, int K, float* __restrict__ basis, int rp = 64) {
   const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= D) return;
   const long blk = c / BG_BLK;
   const int q = (int)(c - blk * BG_BLK);
-  for (int k = 0; k < K; ++k) basis[c * K + k] = ubt[blk * 64 * BG_BLK + (long)k * BG_BLK + q];
+  for (int k = 0; k < K; ++k) basis[c * K + k] = ubt[blk * rp * BG_BLK + (long)k * BG_BLK + q];
 }
 
 struct bg_plan {
-  int nblk;
+  int nblk, rp;
   long ld;
   float *omT, *ypart, *yt, *qt, *bpart, *bm;
   double *gblk, *gsum, *nmat, *lam;
+  void* eig_ws;
+  size_t eig_ws_bytes;
   size_t zero_bytes;
 };
 
-static void plan_bg(pmd_arena& ar, bg_plan& p, long D, int n) {
+// rp = 64 rows of every [comp][x] array while K + 10 <= 64, pmd_tile_rpad(K) beyond (wide.hip kernels)
+static void plan_bg(pmd_arena& ar, bg_plan& p, long D, int n, int K) {
   p.nblk = (int)((D + BG_BLK - 1) / BG_BLK);
   p.ld = pmd_time_ld(n);
-  const size_t nb = p.nblk;
-  p.omT = ar.take_n<float>(64 * p.ld);
-  p.ypart = ar.take_n<float>(nb * XBT_SLICES * 64 * BG_BLK);
-  p.yt = ar.take_n<float>(nb * 64 * BG_BLK);
-  p.qt = ar.take_n<float>(nb * 64 * BG_BLK);
+  p.rp = pmd_tile_rpad(K);
+  const size_t nb = p.nblk, rp = p.rp;
+  const bool wide = p.rp > 64;
+  p.omT = ar.take_n<float>(rp * p.ld);
+  p.ypart = wide ? nullptr : ar.take_n<float>(nb * XBT_SLICES * 64 * BG_BLK);
+  p.yt = ar.take_n<float>(nb * rp * BG_BLK);
+  p.qt = ar.take_n<float>(nb * rp * BG_BLK);
   p.zero_bytes = ar.used;
-  p.bpart = ar.take_n<float>(nb * 64 * p.ld);
-  p.bm = ar.take_n<float>(64 * p.ld);
-  p.gblk = ar.take_n<double>(nb * 4096);
-  p.gsum = ar.take_n<double>(4096);
-  p.nmat = ar.take_n<double>(4096);
-  p.lam = ar.take_n<double>(64);
+  p.bpart = ar.take_n<float>(nb * rp * p.ld);
+  p.bm = ar.take_n<float>(rp * p.ld);
+  p.gblk = ar.take_n<double>(nb * rp * rp);
+  p.gsum = ar.take_n<double>(rp * rp);
+  p.nmat = ar.take_n<double>(rp * rp);
+  p.lam = ar.take_n<double>(rp);
+  p.eig_ws = nullptr;
+  p.eig_ws_bytes = 0;
+  if (wide) {
+    p.eig_ws_bytes = pmd_wide_eig_workspace_bytes(p.rp, 1);
+    p.eig_ws = ar.take(p.eig_ws_bytes);
+  }
 }
 
-size_t pmd_bg_workspace_bytes_impl(long D, int n) {
+size_t pmd_bg_workspace_bytes_impl(long D, int n, int K) {
   pmd_arena ar((void*)0x1000, ~size_t(0) >> 1);
   bg_plan p;
-  plan_bg(ar, p, D, n);
+  plan_bg(ar, p, D, n, K);
   return ar.used + 4096;
+}
+
+// background rSVD with a sketch wider than 64 columns: same steps, generic-width kernels (wide.hip); the tall-skinny
+// orthonormalisation is two rounds of (block Gram matrices, summed) -> eigen-whitening -> row mixing
+static int background_rsvd_wide(pmd_ctx* ctx, const bg_plan& p, const float* xs, long D, int n, long ld, int K, int l, uint64_t seed,
+                                float* basis_out, void* ws) {
+  const int rp = p.rp, nblk = p.nblk;
+  const long srb = (long)rp * BG_BLK, rp2 = (long)rp * rp;
+  PMD_HIP(ctx, hipMemsetAsync(ws, 0, p.zero_bytes, ctx->stream));
+  RUN(pmd_launch_rng(ctx, seed, PMD_STREAM_BG_OMEGA, 0, 0, 1, n, l, 1, p.omT, p.ld, 0));
+  RUN(pmd_launch_tile_xbt_rp(ctx, xs, ld, nullptr, 0, BG_BLK, BG_BLK, p.omT, 0, p.ld, p.yt, srb, 0, BG_BLK, nblk, n, 1, l));
+  const float* src = p.yt;
+  for (int pass = 0; pass < 2; ++pass) {
+    RUN(pmd_launch_wide_gram(ctx, src, srb, BG_BLK, BG_BLK, nblk, 1, rp, p.gblk));
+    hipLaunchKernelGGL(sum_gram_blocks_kernel, dim3((unsigned)((rp2 + 255) / 256)), dim3(256), 0, ctx->stream, p.gblk, nblk, p.gsum, (int)rp2);
+    PMD_LAUNCH_CHECK(ctx, "sum_gram_blocks_kernel");
+    RUN(pmd_launch_wide_eig(ctx, p.gsum, 1, rp, l, 1, 1e-13, p.nmat, p.lam, 1, p.eig_ws, p.eig_ws_bytes));
+    RUN(pmd_launch_wide_rowmix(ctx, src, srb, BG_BLK, p.nmat, 0, rp, l, l, p.qt, srb, BG_BLK, BG_BLK, nblk));
+    src = p.qt;
+  }
+  RUN(pmd_launch_tile_atx_rp(ctx, xs, ld, nullptr, 0, BG_BLK, BG_BLK, p.qt, srb, BG_BLK, p.bpart, (long)rp * p.ld, p.ld, nblk, n, 1, l));
+  RUN(pmd_launch_reduce_slices(ctx, p.bpart, 0, (long)rp * p.ld, nblk, (long)rp * p.ld, p.bm, 0, 1));
+  RUN(pmd_launch_wide_gram(ctx, p.bm, 0, p.ld, n, 1, 1, rp, p.gblk));
+  RUN(pmd_launch_wide_eig(ctx, p.gblk, 1, rp, l, 0, 0.0, p.nmat, p.lam, 1, p.eig_ws, p.eig_ws_bytes));
+  RUN(pmd_launch_wide_rowmix(ctx, p.qt, srb, BG_BLK, p.nmat, 0, rp, l, K, p.qt, srb, BG_BLK, BG_BLK, nblk));
+  hipLaunchKernelGGL(unblock_basis_kernel, dim3((unsigned)((D + 255) / 256)), dim3(256), 0, ctx->stream, p.qt, D, K, basis_out, rp);
+  PMD_LAUNCH_CHECK(ctx, "unblock_basis_kernel");
+  return PMD_OK;
 }
 
 // xs: standardised sample, pixel-major [c][f], leading dimension ld >= pmd_time_ld(n), with
@@ -465,12 +587,13 @@ size_t pmd_bg_workspace_bytes_impl(long D, int n) {
 int pmd_background_rsvd_impl(pmd_ctx* ctx, const float* xs, long D, int n, long ld, int K, uint64_t seed,
                              float* basis_out, void* ws, size_t ws_bytes) {
   const int l = K + 10;
-  if (K < 1 || l > 64) return pmd_fail(ctx, PMD_ERR_UNSUPPORTED, "pmd_background_rsvd", "background_rank must be in [1, 54]");
+  if (K < 1 || K > 64) return pmd_fail(ctx, PMD_ERR_UNSUPPORTED, "pmd_background_rsvd", "background_rank must be in [1, 64]");
   if (ld < pmd_time_ld(n)) return pmd_fail(ctx, PMD_ERR_ARG, "pmd_background_rsvd", "leading dimension too small");
   pmd_arena ar(ws, ws_bytes);
   bg_plan p;
-  plan_bg(ar, p, D, n);
+  plan_bg(ar, p, D, n, K);
   if (ar.overflow) return pmd_fail(ctx, PMD_ERR_WORKSPACE, "pmd_background_rsvd", "workspace too small");
+  if (p.rp > 64) return background_rsvd_wide(ctx, p, xs, D, n, ld, K, l, seed, basis_out, ws);
   const long s64b = 64L * BG_BLK;
   const int nblk = p.nblk;
   PMD_HIP(ctx, hipMemsetAsync(ws, 0, p.zero_bytes, ctx->stream));

@@ -52,9 +52,26 @@ int pmd_launch_expand_pooled(pmd_ctx* ctx, const float* In, long in_tile_stride,
                              const float* pool_w, int d, int r, float* Out, long out_tile_stride, int out_ld,
                              int n_tiles);
 int pmd_launch_stats_roughness(pmd_ctx* ctx, const float* Ut, long u_tile_stride, int u_ld, int b1, int b2,
-                               const float* V, long v_tile_stride, long v_ld, int T, int r, float* stats, int n_tiles);
+                               const float* V, long v_tile_stride, long v_ld, int T, int r, float* stats, int n_tiles,
+                               int rp = PMD_RPAD);
 int pmd_launch_decide(pmd_ctx* ctx, const float* stats, int r, float thr_s, float thr_t, int max_fail, int cap,
-                      int n_tiles, int* good, int* keep, int* ranks);
+                      int n_tiles, int* good, int* keep, int* ranks, int rp = PMD_RPAD);
+
+// wide.hip: generic-width forms (per-tile arrays [tile][rp][x], rp = pmd_tile_rpad(r) > 64)
+extern "C" int pmd_tile_rpad(int r);
+int pmd_launch_wide_gram(pmd_ctx* ctx, const float* In, long tile_stride, long ld, int len, int n_tiles, int slices, int rp,
+                         double* G);
+size_t pmd_wide_eig_workspace_bytes(int n, int n_tiles);
+int pmd_launch_wide_eig(pmd_ctx* ctx, const double* G, int slices, int rp, int n, int mode, double tol, double* Nout,
+                        double* lam_out, int n_tiles, void* ws, size_t ws_bytes);
+int pmd_launch_wide_rowmix(pmd_ctx* ctx, const float* In, long in_tile_stride, long ld_in, const double* N, long n_tile_stride,
+                           int rp, int n_in, int n_out, float* Out, long out_tile_stride, long ld_out, int len, int n_tiles);
+int pmd_launch_tile_atx_rp(pmd_ctx* ctx, const float* X, long ldx, const int* pix, int pix_stride, long row0_stride, int d,
+                           const float* A, long a_tile_stride, int a_ld, float* Out, long out_tile_stride, long ldo, int n_tiles,
+                           int T, int slices, int nrows);
+int pmd_launch_tile_xbt_rp(pmd_ctx* ctx, const float* X, long ldx, const int* pix, int pix_stride, long row0_stride, int d,
+                           const float* B, long b_tile_stride, long ldb, float* S, long s_tile_stride, long s_slice_stride, int s_ld,
+                           int n_tiles, int T, int slices, int nrows);
 
 // expand.hip
 int pmd_csr_rows_spmm_impl(pmd_ctx* ctx, const long* indptr, const int* indices, const float* data, const int* rows,
@@ -88,7 +105,7 @@ int pmd_tiles_hook_offsets_impl(int n, int d, int P, int r, int a, int t_crop, l
 size_t pmd_sim_workspace_bytes_impl(int d, int t, int iters);
 int pmd_threshold_sim_impl(pmd_ctx* ctx, int b1, int b2, int t, int iters, uint64_t seed, float* stats_out, void* ws,
                            size_t ws_bytes);
-size_t pmd_bg_workspace_bytes_impl(long D, int n);
+size_t pmd_bg_workspace_bytes_impl(long D, int n, int K);
 int pmd_background_rsvd_impl(pmd_ctx* ctx, const float* xs, long D, int n, long ld, int K, uint64_t seed,
                              float* basis_out, void* ws, size_t ws_bytes);
 
@@ -135,7 +152,7 @@ int pmd_csr_count_impl(pmd_ctx* ctx, int d1, int d2, int order_f, const int* cov
 int pmd_csr_fill_impl(pmd_ctx* ctx, int d1, int d2, int order_f, int b1, const int* cover1, const int* cover2,
                       const int* orig1, const int* orig2, int n2, const int* ranks, const int* col_off, const float* Ut,
                       int dpad, const float* w, const double* inv_cumw, const float* basis, int K, int Rt,
-                      const long* indptr, double* data, int* indices, int* zero_count);
+                      const long* indptr, double* data, int* indices, int* zero_count, int rpad);
 size_t pmd_orthogonalize_factored_workspace_bytes_impl(int m);
 int pmd_orthogonalize_factored_impl(pmd_ctx* ctx, const float* M, int Rc, int m, long ldm, const float* GM, long ldgm,
                                     float* Et_out, long lde, int* rprime_out, void* ws, size_t ws_bytes);

@@ -397,7 +397,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 
 // evaluation.py:84-111.  Ut: [tile][comp][q], q = i + b1*j.  One wave per (tile, comp).
 __global__ __launch_bounds__(64) void spatial_stat_kernel(const float* __restrict__ Ut, long tile_stride, int ld, int b1,
-                                                          int b2, float* __restrict__ stats) {
+                                                          int b2, float* __restrict__ stats, int rp) {
   const int tile = blockIdx.y, comp = blockIdx.x;
   const float* u = Ut + (long)tile * tile_stride + (long)comp * ld;
   const int d = b1 * b2;
@@ -413,13 +413,13 @@ __global__ __launch_bounds__(64) void spatial_stat_kernel(const float* __restric
   if (threadIdx.x == 0) {
     const float avg_diff = (sv + sh) / (float)((b1 - 1) * b2 + b1 * (b2 - 1));
     const float avg_elem = sa / (float)d;
-    stats[((long)tile * PMD_RPAD + comp) * 2 + 0] = avg_diff / avg_elem;
+    stats[((long)tile * rp + comp) * 2 + 0] = avg_diff / avg_elem;
   }
 }
 
 // evaluation.py:114-126.  V: [tile][comp][t].  One workgroup per (tile, comp).
 __global__ __launch_bounds__(256) void temporal_stat_kernel(const float* __restrict__ V, long tile_stride, long ld, int T,
-                                                            float* __restrict__ stats) {
+                                                            float* __restrict__ stats, int rp) {
   __shared__ float red[2][4];
   const int tile = blockIdx.y, comp = blockIdx.x;
   const float* v = V + (long)tile * tile_stride + (long)comp * ld;
@@ -435,24 +435,24 @@ __global__ __launch_bounds__(256) void temporal_stat_kernel(const float* __restr
   if (threadIdx.x == 0) {
     const float n4 = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
     const float d4 = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
-    stats[((long)tile * PMD_RPAD + comp) * 2 + 1] = (n4 / (float)(T - 2)) / (d4 / (float)T);
+    stats[((long)tile * rp + comp) * 2 + 1] = (n4 / (float)(T - 2)) / (d4 / (float)T);
   }
 }
 
 int pmd_launch_stats_roughness(pmd_ctx* ctx, const float* Ut, long u_tile_stride, int u_ld, int b1, int b2,
                                const float* V, long v_tile_stride, long v_ld, int T, int r, float* stats,
-                               int n_tiles) {
+                               int n_tiles, int rp) {
   pmd_prof_scope prof__(ctx, "roughness");
   for (int t0 = 0; t0 < n_tiles; t0 += 32768) {
     const int tn = (n_tiles - t0 < 32768) ? n_tiles - t0 : 32768;
     if (Ut) {
       hipLaunchKernelGGL(spatial_stat_kernel, dim3(r, tn), dim3(64), 0, ctx->stream, Ut + (long)t0 * u_tile_stride,
-                         u_tile_stride, u_ld, b1, b2, stats + (long)t0 * PMD_RPAD * 2);
+                         u_tile_stride, u_ld, b1, b2, stats + (long)t0 * rp * 2, rp);
       PMD_LAUNCH_CHECK(ctx, "spatial_stat_kernel");
     }
     if (V) {
       hipLaunchKernelGGL(temporal_stat_kernel, dim3(r, tn), dim3(256), 0, ctx->stream, V + (long)t0 * v_tile_stride,
-                         v_tile_stride, v_ld, T, stats + (long)t0 * PMD_RPAD * 2);
+                         v_tile_stride, v_ld, T, stats + (long)t0 * rp * 2, rp);
       PMD_LAUNCH_CHECK(ctx, "temporal_stat_kernel");
     }
   }
@@ -461,16 +461,16 @@ int pmd_launch_stats_roughness(pmd_ctx* ctx, const float* Ut, long u_tile_stride
 
 // evaluation.py:133-164 + :195-222.  keep[tile][c] in {0,1}; ranks[tile] = number kept (capped).
 __global__ void decide_kernel(const float* __restrict__ stats, int r, float thr_s, float thr_t, int max_fail, int cap,
-                              int n_tiles, int* __restrict__ good, int* __restrict__ keep, int* __restrict__ ranks) {
+                              int n_tiles, int* __restrict__ good, int* __restrict__ keep, int* __restrict__ ranks, int rp) {
   const int tile = blockIdx.x * blockDim.x + threadIdx.x;
   if (tile >= n_tiles) return;
   int fails = 0, count = 0;
   bool all_fails = false;
-  for (int c = 0; c < PMD_RPAD; ++c) {
+  for (int c = 0; c < rp; ++c) {
     int g = 0, k = 0;
     if (c < r) {
-      const float sp = stats[((long)tile * PMD_RPAD + c) * 2 + 0];
-      const float tp = stats[((long)tile * PMD_RPAD + c) * 2 + 1];
+      const float sp = stats[((long)tile * rp + c) * 2 + 0];
+      const float tp = stats[((long)tile * rp + c) * 2 + 1];
       g = (sp < thr_s) && (tp < thr_t);
       if (all_fails) k = 0;
       else if (!g) {
@@ -484,17 +484,17 @@ __global__ void decide_kernel(const float* __restrict__ stats, int r, float thr_
       if (k && count >= cap) k = 0;
       count += k;
     }
-    good[(long)tile * PMD_RPAD + c] = g;
-    keep[(long)tile * PMD_RPAD + c] = k;
+    good[(long)tile * rp + c] = g;
+    keep[(long)tile * rp + c] = k;
   }
   ranks[tile] = count;
 }
 
 int pmd_launch_decide(pmd_ctx* ctx, const float* stats, int r, float thr_s, float thr_t, int max_fail, int cap,
-                      int n_tiles, int* good, int* keep, int* ranks) {
+                      int n_tiles, int* good, int* keep, int* ranks, int rp) {
   pmd_prof_scope prof__(ctx, "decide");
   hipLaunchKernelGGL(decide_kernel, dim3((n_tiles + 63) / 64), dim3(64), 0, ctx->stream, stats, r, thr_s, thr_t,
-                     max_fail, cap, n_tiles, good, keep, ranks);
+                     max_fail, cap, n_tiles, good, keep, ranks, rp);
   PMD_LAUNCH_CHECK(ctx, "decide_kernel");
   return PMD_OK;
 }

@@ -362,7 +362,10 @@ int pmd_launch_tile_atx(pmd_ctx* ctx, const float* X, long ldx, const int* pix, 
     if (d > 2048) return pmd_fail(ctx, PMD_ERR_UNSUPPORTED, "tile_atx", "tile larger than 2048 pixels");
     kz = 2;
     dv = 1024;
-    PMD_HIP(ctx, hipMemsetAsync(Out, 0, (size_t)n_tiles * out_tile_stride * sizeof(float), ctx->stream));
+    // the two K halves accumulate with atomics: clear the 64 output rows of every tile (only those: the tile stride may
+    // cover more row blocks than this call writes, pmd_launch_tile_atx_rp)
+    PMD_HIP(ctx, hipMemset2DAsync(Out, (size_t)out_tile_stride * sizeof(float), 0, (size_t)PMD_RPAD * ldo * sizeof(float), (size_t)n_tiles,
+                                  ctx->stream));
   }
   pmd_dvariant v;
   if (!pmd_pick_dvariant(dv, &v)) return pmd_fail(ctx, PMD_ERR_UNSUPPORTED, "tile_atx", "no kernel variant");

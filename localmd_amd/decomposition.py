@@ -260,6 +260,15 @@ def _sparse_u(ut_host, ranks, pix_f, block_weights, inv_cumw_rows, n_rows):
     return u_r, offsets
 
 
+def _virtual_ranks(ranks_dev, nvt):
+    """ranks of the blocks of 64 component rows of every tile: tile t with rank k -> min(max(k - 64 h, 0), 64), h < nvt."""
+    torch = _torch()
+    if nvt == 1:
+        return ranks_dev
+    h = 64 * torch.arange(nvt, device=ranks_dev.device, dtype=ranks_dev.dtype)
+    return torch.clamp(ranks_dev[:, None] - h[None, :], 0, 64).reshape(-1).contiguous()
+
+
 def _apply_hook(fn, arr):
     """arr: (n_tiles, ...) device view.  The reference calls the denoiser once per block (decomposition.py:300, :310);
     a callable with a true ``batched`` attribute receives all tiles at once instead."""
@@ -286,6 +295,7 @@ def _tiles_decompose(ctx, args, ws, hook_geom, temporal_denoiser, spatial_denois
         ctx.call("pmd_tiles_decompose", *args, ptr(ws), ws.numel())
         return
     n, b1, b2, P_pool, r, a_f, t_crop, ldv, n_rows, dpad = hook_geom
+    rp = ctx.lib.pmd_tile_rpad(r)
     import ctypes as C
 
     off_v, off_s = C.c_size_t(0), C.c_size_t(0)
@@ -294,8 +304,8 @@ def _tiles_decompose(ctx, args, ws, hook_geom, temporal_denoiser, spatial_denois
         raise ValueError("pmd_tiles_hook_offsets failed ({})".format(rc))
     flat = ws.view(torch.uint8).reshape(-1)
     r = min(r, t_crop // a_f, P_pool, r + 10)   # the components that exist (pmd_tiles_decompose: bins / pooled pixels may be fewer)
-    vds = flat[off_v.value:off_v.value + n * 64 * ldv * 4].view(torch.float32).view(n, 64, ldv)[:, :r, :t_crop]
-    s_arr = flat[off_s.value:off_s.value + n * 64 * dpad * 4].view(torch.float32).view(n, 64, dpad)[:, :r, :b1 * b2]
+    vds = flat[off_v.value:off_v.value + n * rp * ldv * 4].view(torch.float32).view(n, rp, ldv)[:, :r, :t_crop]
+    s_arr = flat[off_s.value:off_s.value + n * rp * dpad * 4].view(torch.float32).view(n, rp, dpad)[:, :r, :b1 * b2]
     ctx.call("pmd_tiles_decompose_staged", *args, ptr(ws), ws.numel(), 1)
     if temporal_denoiser is not None:
         _apply_hook(temporal_denoiser, vds)
@@ -493,6 +503,8 @@ def localmd_decomposition(
 
         t0 = time.perf_counter()
         K = int(background_rank)
+        if K > 64:
+            raise ValueError("background_rank must be <= 64 in the HIP pipeline (got {})".format(K))
         basis_dev = None
         if K > 0:
             sample = dist.broadcast_object(np.random.choice(list(range(T)), replace=False, size=min(1000, T)).tolist())
@@ -505,7 +517,7 @@ def localmd_decomposition(
                 dist.gather_runs(xs_all, owned)
                 xs_s = xs_all
             basis_dev = torch.empty((D, K), dtype=torch.float32, device=ctx.device)
-            ws = ctx.workspace(lib.pmd_background_rsvd_workspace_bytes(D, len(sample)))
+            ws = ctx.workspace(lib.pmd_background_rsvd_workspace_bytes(D, len(sample), K))
             ctx.call("pmd_background_rsvd", ptr(xs_s), D, len(sample), ld_s, K, seed, ptr(basis_dev), ptr(ws), ws.numel())
             del xs_s
         lap("background", t0)
@@ -628,20 +640,26 @@ def localmd_decomposition(
         dpad = lib.pmd_tile_dpad(d)
         if dpad < 0 or lib.pmd_tile_dpad(P_pool) < 0:
             raise ValueError("block of {} x {} pixels is larger than the supported maximum (2048 pixels)".format(b1, b2))
-        if max_components + 10 > 64:
-            raise ValueError("max_components must be <= 54 in the HIP pipeline (got {})".format(max_components))
+        # Component rows of the per-tile arrays: 64 while max_components + 10 <= 64 (the MFMA-tiled kernels), a larger multiple
+        # of 64 beyond (generic-width kernels, csrc/wide.hip) - max_components is unbounded, as in the reference
+        # (decomposition.py:643-665).  The global stage works on blocks of 64 component rows: an array with rpad = 64 nvt rows is
+        # handed to it as nvt "virtual tiles" per tile, [n * nvt][64][x], the same memory (see below, after the assembly).
+        rpad = int(lib.pmd_tile_rpad(int(max_components)))
+        nvt = rpad // 64
+        if nvt > 1 and n_win > 1:
+            raise ValueError("window_chunks < frame_range (residual windows) is supported up to max_components = 54 (got {})".format(max_components))
         pix_dev = _i32(ctx, pix_c)
         pool_q_dev, pool_idx_dev, pool_w_dev = _i32(ctx, pool_q), _i32(ctx, pool_idx), _f32(ctx, pool_w)
 
         t0 = time.perf_counter()
         r = int(max_components)
         ldv = ld_f
-        ut_dev = torch.empty((n_tiles, 64, dpad), dtype=torch.float32, device=ctx.device)
-        stats_dev = torch.zeros((n_tiles, 64, 2), dtype=torch.float32, device=ctx.device)
-        good_dev = torch.zeros((n_tiles, 64), dtype=torch.int32, device=ctx.device)
-        keep_dev = torch.zeros((n_tiles, 64), dtype=torch.int32, device=ctx.device)
+        ut_dev = torch.empty((n_tiles, rpad, dpad), dtype=torch.float32, device=ctx.device)
+        stats_dev = torch.zeros((n_tiles, rpad, 2), dtype=torch.float32, device=ctx.device)
+        good_dev = torch.zeros((n_tiles, rpad), dtype=torch.int32, device=ctx.device)
+        keep_dev = torch.zeros((n_tiles, rpad), dtype=torch.int32, device=ctx.device)
         ranks_dev = torch.zeros((n_tiles,), dtype=torch.int32, device=ctx.device)
-        lam_dev = torch.zeros((n_tiles, 64), dtype=torch.float64, device=ctx.device)
+        lam_dev = torch.zeros((n_tiles, rpad), dtype=torch.float64, device=ctx.device)
         assert n_tiles == n1_geo * n2_geo
         t_lo, t_hi = runs[dist.rank] if dist.enabled else (0, n_tiles)
         if not dist.enabled:
@@ -661,11 +679,11 @@ def localmd_decomposition(
         # grow with tiles x frames: 84 GB each at BASELINE config 5 (65 025 tiles x 5 000 frames).  Above
         # `tile_batch_bytes` the tiles are fitted (and later projected) in batches whose traces are compacted to the
         # kept components right away; one batch (every workload up to config 3's size) is the single-launch path.
-        per_tile_bytes = 3 * 64 * int(max(ldv, ld_T)) * 4 + 8 * 64 * dpad * 4
+        per_tile_bytes = 3 * rpad * int(max(ldv, ld_T)) * 4 + 8 * rpad * dpad * 4 + (6 * rpad * rpad * 8 if nvt > 1 else 0)
         tile_batch = max(8, int(tile_batch_bytes // per_tile_bytes))
         batches = [(b0, min(n_loc, b0 + tile_batch)) for b0 in range(0, max(n_loc, 1), tile_batch)] if n_win == 1 else [(0, n_loc)]
         batched = len(batches) > 1
-        v_dev = None if batched else torch.empty((n_tiles, 64, ldv), dtype=torch.float32, device=ctx.device)
+        v_dev = None if batched else torch.empty((n_tiles, rpad, ldv), dtype=torch.float32, device=ctx.device)
         v_pieces = []
 
         def tiles_args(g0, nb_, v_out, x_rows=None, n_rows=None, pix_rows=None):
@@ -684,7 +702,7 @@ def localmd_decomposition(
         elif n_loc > 0 and n_win == 1:
             for b0, b1_ in batches:
                 nb_, g0 = b1_ - b0, t_lo + b0
-                vb = torch.empty((nb_, 64, ldv), dtype=torch.float32, device=ctx.device)
+                vb = torch.empty((nb_, rpad, ldv), dtype=torch.float32, device=ctx.device)
                 # the band of resident pixels the batch touches (tiles are in tile-row order): the temporal binning of the
                 # sketch walks only these rows instead of the whole movie once per batch (409 ms of 1.46 s at config 5)
                 lo_pix = int(pix_c[g0:g0 + nb_].min()) - P_lo
@@ -693,11 +711,11 @@ def localmd_decomposition(
                 ws = ctx.workspace(lib.pmd_tiles_workspace_bytes(nb_, b1, b2, P_pool, r, a_f, crop, ldv, n_band))
                 _tiles_decompose(ctx, tiles_args(g0, nb_, vb, xf[lo_pix:], n_band, pix_b), ws,
                                  (nb_, b1, b2, P_pool, r, a_f, crop, ldv, n_band, dpad), temporal_denoiser, spatial_denoiser)
-                rk = ranks_dev[g0:g0 + nb_]
+                rk = _virtual_ranks(ranks_dev[g0:g0 + nb_], nvt)     # blocks of 64 component rows
                 off_b = (torch.cumsum(rk, 0) - rk).to(torch.int32)
                 rows_b = int(rk.sum().item())
                 piece = torch.zeros((max(rows_b, 1), crop), dtype=torch.float32, device=ctx.device)
-                ctx.call("pmd_compact_rows", ptr(vb), ldv, ptr(off_b), ptr(rk), crop, ptr(piece), crop, nb_)
+                ctx.call("pmd_compact_rows", ptr(vb), ldv, ptr(off_b), ptr(rk), crop, ptr(piece), crop, nb_ * nvt)
                 v_pieces.append(piece[:rows_b])
                 del vb
             ctx.release_workspace()     # the batch workspace (GBs) is not needed again
@@ -769,7 +787,7 @@ def localmd_decomposition(
         zero_dev = torch.zeros(1, dtype=torch.int32, device=ctx.device)
         ctx.call("pmd_csr_fill", d1, d2, order_f, b1, ptr(cov1_dev), ptr(cov2_dev), ptr(o1_dev), ptr(o2_dev), n2,
                  ptr(ranks_dev), ptr(col_off_dev), ptr(ut_dev), dpad, ptr(w_dev), ptr(inv_cumw_dev), ptr(basis_dev),
-                 max(K, 0), Rt, ptr(indptr_dev), ptr(data_dev), ptr(idx_dev), ptr(zero_dev))
+                 max(K, 0), Rt, ptr(indptr_dev), ptr(data_dev), ptr(idx_dev), ptr(zero_dev), rpad)
         ut_host = None
         basis_rows = None
         u_pending = None
@@ -804,6 +822,26 @@ def localmd_decomposition(
         display("Normalizing by weights")
         display("The total rank before pruning is {}".format(R))
         lap("assembly", t0)
+        tile_ranks_out = ranks.astype(np.int32)
+        if nvt > 1:
+            # From here on a "tile" is a block of 64 component rows: tile t with rpad = 64 nvt rows becomes the nvt virtual tiles
+            # t nvt + h (same pixels, components 64 h .. 64 h + 63), in the same memory.  Column order, and with it every row
+            # index of the global stage, is unchanged; two virtual tiles of one tile overlap on all of its pixels.
+            ranks = np.clip(ranks[:, None] - 64 * np.arange(nvt)[None, :], 0, 64).reshape(-1)
+            offsets = np.concatenate([[0], np.cumsum(ranks)]).astype(np.int64)
+            ranks_dev = _virtual_ranks(ranks_dev, nvt)
+            col_off_dev = _i32(ctx, offsets[:-1])
+            ut_dev = ut_dev.view(n_tiles * nvt, 64, dpad)
+            if v_dev is not None:
+                v_dev = v_dev.view(n_tiles * nvt, 64, ldv)
+            pix_c = np.repeat(pix_c, nvt, axis=0)
+            origins = np.repeat(np.asarray(origins), nvt, axis=0)
+            pix_dev = pix_dev.repeat_interleave(nvt, dim=0)
+            pix_loc_dev = pix_loc_dev.repeat_interleave(nvt, dim=0) if dist.enabled else pix_dev
+            pairs = grid.virtual_pairs(pairs, nvt)
+            runs = [(lo * nvt, hi * nvt) for lo, hi in runs]
+            batches = [(lo * nvt, hi * nvt) for lo, hi in batches]
+            n_tiles, t_lo, t_hi, n_loc = n_tiles * nvt, t_lo * nvt, t_hi * nvt, n_loc * nvt
 
         # ---- orthogonalisation (decomposition.py:860-881)
         display("Performing rank pruning and orthogonalization for fast sparse regression.")
@@ -1252,9 +1290,9 @@ def localmd_decomposition(
             return final_movie
         diag = {
             "seed": seed, "frames": list(frames), "thresholds": (float(spatial_threshold), float(temporal_threshold)),
-            "sim_stats": sim_stats, "tile_ranks": ranks.astype(np.int32), "tile_stats": stats_dev.cpu().numpy(),
+            "sim_stats": sim_stats, "tile_ranks": tile_ranks_out, "tile_stats": stats_dev.cpu().numpy(),
             "tile_good": good_dev.cpu().numpy(), "tile_keep": keep_dev.cpu().numpy(), "tile_lambda": lam_dev.cpu().numpy(),
-            "tile_ut": ut_dev.cpu().numpy(), "origins": origins, "pix": pix_c, "block_weights": block_weights,
+            "tile_ut": ut_dev.cpu().numpy().reshape(len(tile_ranks_out), rpad, dpad), "origins": origins[::nvt], "pix": pix_c[::nvt], "block_weights": block_weights,
             "max_components": r, "rank_before": R, "rank_after": rp + (1 if null_tail else 0), "timings": timings,
             "orthogonalizer": ("cholesky" if (use_right and chol_ok) else "eigh"),
             "crop": crop, "dpad": dpad, "v_proj": Vp.cpu().numpy(), "eig_order": min(rp, T), "col_sigma": col_sigma, "n_tile_cols": Rt,

@@ -163,6 +163,24 @@ def overlap_pairs(origins, block_sizes):
     return np.ascontiguousarray(out, dtype=np.int32).reshape(-1, 6)
 
 
+def virtual_pairs(pairs, vt):
+    """overlap_pairs for tiles split into vt blocks of 64 component rows each ("virtual tiles" t * vt + h, all with the
+    pixels of tile t): every pair (a, b) becomes the vt x vt pairs of their blocks, a pair (a, a) the pairs (h <= g) of its
+    own blocks; same intersection rectangles, ordered by (a, b)."""
+    if vt == 1:
+        return pairs
+    pairs = np.asarray(pairs, dtype=np.int64)
+    h, g = np.meshgrid(np.arange(vt), np.arange(vt), indexing="ij")
+    h, g = h.reshape(-1), g.reshape(-1)
+    ta = (pairs[:, 0:1] * vt + h[None, :]).reshape(-1)
+    tb = (pairs[:, 1:2] * vt + g[None, :]).reshape(-1)
+    rect = np.repeat(pairs[:, 2:], vt * vt, axis=0)
+    keep = tb >= ta
+    out = np.concatenate([ta[:, None], tb[:, None], rect], axis=1)[keep]
+    out = out[np.lexsort((out[:, 1], out[:, 0]))]
+    return np.ascontiguousarray(out, dtype=np.int32).reshape(-1, 6)
+
+
 def cumulative_weights(fov, block_sizes, origins, block_weights):
     """Sum of the tile weights covering each pixel (decomposition.py:813-816), float64 (d1, d2)."""
     cw = np.zeros(fov, dtype=np.float64)

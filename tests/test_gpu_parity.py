@@ -106,7 +106,7 @@ def test_background_rsvd(gpu_ctx):
     xs[:D, :T] = dev(ctx, xs_np)
     seed = 77
     basis = torch.empty((D, K), dtype=torch.float32, device=ctx.device)
-    ws = ctx.workspace(ctx.lib.pmd_background_rsvd_workspace_bytes(D, T))
+    ws = ctx.workspace(ctx.lib.pmd_background_rsvd_workspace_bytes(D, T, K))
     ctx.call("pmd_background_rsvd", P(xs), D, T, ld, K, seed, P(basis), P(ws), ws.numel())
     ctx.sync()
     src = DeviceSource(ctx, seed)
@@ -309,6 +309,43 @@ def test_full_pipeline_small(gpu_ctx):
     _, _, sp, tp = O.threshold_heuristic([20, 20, 600], DeviceSource(gpu_ctx, 123), iters=20)
     np.testing.assert_allclose(diag["sim_stats"][:, 0], sp, rtol=2e-4)
     np.testing.assert_allclose(diag["sim_stats"][:, 1], tp, rtol=2e-4)
+
+
+def test_full_pipeline_max_components_80(gpu_ctx):
+    """max_components is unbounded in the reference (decomposition.py:643-665; the rSVD at :59-67 takes any rank): beyond
+    54 the sketch (max_components + 10 columns) no longer fits the 64 component rows of the MFMA-tiled kernels and the tile
+    stage runs the generic-width kernels (csrc/wide.hip) on 128-row arrays.  Same checks as every other configuration."""
+    mov = _movie(1200, 40, 50, seed=21)
+    pmd, diag, ref = _compare_full(gpu_ctx, mov, (20, 20), 1200, max_components=80, background_rank=3, sim_iters=10)
+    assert diag["max_components"] == 80 == ref.diag["max_components"]
+    _check_full(pmd, diag, ref, mov)
+
+
+def test_full_pipeline_max_components_80_every_component_kept(gpu_ctx):
+    """The same with thresholds that every component passes: all 80 components of every tile are kept, so each tile spans
+    two blocks of 64 component rows in the global stage (virtual tiles: Gram blocks between the two blocks of one tile,
+    compaction, projection, CSR assembly with 80 columns per tile), first with R <= frames, then with R > frames."""
+    mov = _movie(1000, 40, 50, seed=22)
+    pmd, diag, ref = _compare_full(gpu_ctx, mov, (20, 20), 1000, max_components=80, background_rank=2, thresholds=(1e9, 1e9))
+    assert np.all(diag["tile_ranks"] == 80) and np.all(ref.diag["tile_ranks"] == 80)
+    assert pmd.u.shape[1] == 12 * 80 + 2 and diag["rank_before"] <= diag["crop"]
+    # (every tile is cut at component 80 inside its cluster of noise-level singular values, so the span of a tile's kept
+    # components is determined only up to that cluster: the last few of the 962 final components - s ~ 2e-3 s_1 - are
+    # individually ill-determined on both sides; vt_tol scales the per-component bound eps s_1 / (s_c gap_c))
+    _check_full(pmd, diag, ref, mov, vt_tol=2e-2)
+    mov = _movie(900, 40, 70, seed=23)
+    pmd, diag, ref = _compare_full(gpu_ctx, mov, (20, 20), 900, max_components=80, background_rank=2, thresholds=(1e9, 1e9))
+    assert np.all(diag["tile_ranks"] == 80) and diag["rank_before"] > diag["crop"]
+    _check_full(pmd, diag, ref, mov, vt_tol=2e-2, orth_tol=1e-2, s_tol=3e-3, vt_tol_signal=2e-3, probe_tol=5e-3)
+
+
+def test_full_pipeline_background_rank_60(gpu_ctx):
+    """background_rank = 60: a 70-column sketch of the standardised sample (pmd_loader.py:46-68), generic-width kernels in
+    the background rSVD; 60 background columns in U, 60 background rows in the temporal matrix."""
+    mov = _movie(800, 60, 60, seed=24)
+    pmd, diag, ref = _compare_full(gpu_ctx, mov, (20, 20), 800, max_components=6, background_rank=60, sim_iters=10)
+    assert pmd.u.shape[1] == int(diag["tile_ranks"].sum()) + 60
+    _check_full(pmd, diag, ref, mov, vt_tol=3e-3)
 
 
 def test_full_pipeline_subsampled_frames_and_no_background(gpu_ctx):
