@@ -21,6 +21,8 @@ int pmd_ctx_create(int device, void* hip_stream, pmd_ctx** out) {
   ctx->tables = nullptr;
   ctx->scratch = nullptr;
   ctx->scratch_bytes = 0;
+  ctx->scratch2 = nullptr;
+  ctx->scratch2_bytes = 0;
   ctx->split_ws = nullptr;
   ctx->split_ws_bytes = 0;
   {
@@ -53,6 +55,7 @@ int pmd_ctx_destroy(pmd_ctx* ctx) {
   if (ctx->comm) pmd_comm_destroy_impl(ctx);
   if (ctx->tables) hipFree(ctx->tables);
   if (ctx->scratch) hipFree(ctx->scratch);
+  if (ctx->scratch2) hipFree(ctx->scratch2);
   if (ctx->split_ws) hipFree(ctx->split_ws);
   if (ctx->blas) rocblas_destroy_handle(ctx->blas);
   delete ctx;

@@ -106,6 +106,23 @@ __global__ void sum_partials_kernel(const float* __restrict__ part, long mn, int
   }
 }
 
+// Length of one fp32 accumulation chain in the library's GEMM-shaped products (PMD_GEMM_KCHUNK overrides; 0 = whole k):
+// 1024 up to k = 16384, 2048 beyond (the output is re-read once per chunk: 12 % / 6 % of the product's time).
+int pmd_gemm_k_chunk(int k) {
+  static int forced = -2;
+  if (forced == -2) { const char* e = getenv("PMD_GEMM_KCHUNK"); forced = e ? atoi(e) : -1; }
+  if (forced == 0) return k;
+  if (forced > 0) return forced;
+  if (k <= 3072) return k;
+  return k <= 16384 ? 1024 : 2048;
+}
+
+bool pmd_is_host_pointer(const void* p) {
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+  return attr.type == hipMemoryTypeHost;
+}
+
 static int gemm_rm_splitk(pmd_ctx* ctx, int transA, int transB, int m, int n, int k, int S, float alpha, const float* A, long lda,
                           const float* B, long ldb, float beta, float* C, long ldc) {
   pmd_prof_scope prof__(ctx, "rocblas_sgemm_splitk");
@@ -155,6 +172,25 @@ int pmd_gemm_rm(pmd_ctx* ctx, int transA, int transB, int m, int n, int k, float
     }
   }
   pmd_prof_scope prof__(ctx, "rocblas_sgemm");
+  const int kc = pmd_gemm_k_chunk(k);
+  if (kc < k && !pmd_is_host_pointer(C)) {
+    // Long inner dimension: rocBLAS carries ONE fp32 accumulation chain over all of k (measured on MI355X, scripts/
+    // gemm_bias_probe.py: entry errors of 4.9e-6 of the diagonal at k = 10^4, against 3.8e-7 when the chain is cut every
+    // 1024 terms - what a CPU BLAS does through its k blocking, and what the NumPy oracle therefore sees).  On the Gram
+    // matrix of a 2000 x 10^4 trace matrix those entry errors add up to 4e-5 on the leading singular values and 6e-4 on
+    // right singular vectors with 2 % gaps.  Chunks of kc terms accumulated into C (one rounding per chunk).
+    const rocblas_operation opA = transA ? rocblas_operation_transpose : rocblas_operation_none;
+    const rocblas_operation opB = transB ? rocblas_operation_transpose : rocblas_operation_none;
+    const float one = 1.f;
+    for (int k0 = 0; k0 < k; k0 += kc) {
+      const int kk = std::min(kc, k - k0);
+      const float* a = A + (transA ? (long)k0 * lda : (long)k0);
+      const float* b = B + (transB ? (long)k0 : (long)k0 * ldb);
+      PMD_BLAS(ctx, rocblas_sgemm(ctx->blas, opB, opA, n, m, kk, &alpha, b, (rocblas_int)ldb, a, (rocblas_int)lda, k0 == 0 ? &beta : &one, C,
+                                  (rocblas_int)ldc));
+    }
+    return PMD_OK;
+  }
   PMD_BLAS(ctx, rocblas_sgemm(ctx->blas, transB ? rocblas_operation_transpose : rocblas_operation_none,
                               transA ? rocblas_operation_transpose : rocblas_operation_none, n, m, k, &alpha, B,
                               (rocblas_int)ldb, A, (rocblas_int)lda, &beta, C, (rocblas_int)ldc));
@@ -492,12 +528,18 @@ int pmd_projected_svd_impl(pmd_ctx* ctx, const float* P, int rows_p, long ldp, c
     // Gram matrix: only the row-major upper triangle (= column-major lower), the one pmd_syevd reads
     pmd_prof_scope prof__(ctx, "rocblas_ssyrk");
     const float one = 1.f, zero = 0.f;
-    if (n1 <= n2)  // V V^T
-      PMD_BLAS(ctx, rocblas_ssyrk(ctx->blas, rocblas_fill_lower, rocblas_operation_transpose, n1, n2, &one, V, (rocblas_int)ldv,
-                                  &zero, C, (rocblas_int)ldc));
-    else           // V^T V
-      PMD_BLAS(ctx, rocblas_ssyrk(ctx->blas, rocblas_fill_lower, rocblas_operation_none, n2, n1, &one, V, (rocblas_int)ldv,
-                                  &zero, C, (rocblas_int)ldc));
+    // (inner dimension in chunks: one fp32 accumulation chain per chunk, see pmd_gemm_rm)
+    const int kfull = (n1 <= n2) ? n2 : n1;
+    const int kc = pmd_gemm_k_chunk(kfull);
+    for (int k0 = 0; k0 < kfull; k0 += kc) {
+      const int kk = std::min(kc, kfull - k0);
+      if (n1 <= n2)  // V V^T
+        PMD_BLAS(ctx, rocblas_ssyrk(ctx->blas, rocblas_fill_lower, rocblas_operation_transpose, n1, kk, &one, V + k0, (rocblas_int)ldv,
+                                    k0 == 0 ? &zero : &one, C, (rocblas_int)ldc));
+      else           // V^T V
+        PMD_BLAS(ctx, rocblas_ssyrk(ctx->blas, rocblas_fill_lower, rocblas_operation_none, n2, kk, &one, V + (long)k0 * ldv, (rocblas_int)ldv,
+                                    k0 == 0 ? &zero : &one, C, (rocblas_int)ldc));
+    }
   }
   RUN(pmd_syevd(ctx, nk, C, ldc, w, work, info));
   std::vector<float> hw(nk);

@@ -38,6 +38,8 @@ struct pmd_ctx {
   const char* atx_label;             // profiling name of the next tile_atx launches (NULL: "tile_atx")
   void* scratch;                     // library-owned device scratch of the eigensolver (sytrd.hip)
   size_t scratch_bytes;
+  void* scratch2;                    // library-owned device scratch of the fp64 eigenvector refinement (sytrd.hip)
+  size_t scratch2_bytes;
   int gemm_split;                    // 0: rocBLAS sgemm; 3 / 6: large products as sums of bf16-piece products (opt-in)
   double gemm_split_min_flop;        // ... for products with at least this many flops
   void* split_ws;                    // library-owned device scratch of the split products (bf16 pieces)

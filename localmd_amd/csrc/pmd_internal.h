@@ -112,6 +112,8 @@ int pmd_background_rsvd_impl(pmd_ctx* ctx, const float* xs, long D, int n, long 
 // global.hip
 int pmd_gemm_rm(pmd_ctx* ctx, int transA, int transB, int m, int n, int k, float alpha, const float* A, long lda,
                 const float* B, long ldb, float beta, float* C, long ldc);
+int pmd_gemm_k_chunk(int k);
+bool pmd_is_host_pointer(const void* p);
 int pmd_syevd(pmd_ctx* ctx, int n, float* A, long lda, float* w, float* work, int* info);
 size_t pmd_sy2sb_workspace_bytes_impl(int n);
 int pmd_sy2sb_impl(pmd_ctx* ctx, int n, float* A, long lda, float* tau1, int* flag_host, void* ws, size_t ws_bytes);

@@ -1040,9 +1040,121 @@ static int syevd_f64(pmd_ctx* ctx, int n, float* A, long lda, float* w, int* inf
   return PMD_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// fp64 refinement of an fp32 eigendecomposition (Ogita & Aishima, "Iterative refinement for symmetric eigenvalue
+// decomposition", Japan J. Indust. Appl. Math. 35, 2018).  The fp32 solvers (own tridiagonalisation + sstedc, rocSOLVER
+// ssyevd) return vectors with an error of ~c eps32 lambda_1 / |lambda_i - lambda_j| per pair: 5e-4 on Vt rows whose
+// singular values differ by 2 % (measured: 128 x 128 x 10^4 movie, order 2027), where NumPy - LAPACK in double on the
+// same fp32 matrix - is exact to 1e-6.  With X the computed vectors (columns), in double:
+//     G = X^T X,  S = X^T A X,  lambda~_i = S_ii / G_ii,  R = I - G,
+//     E_ij = (S_ij + lambda~_j R_ij) / (lambda~_j - lambda~_i)   if |lambda~_i - lambda~_j| > delta,   else R_ij / 2,
+//     X <- X + X E
+// converges quadratically for the pairs outside clusters (delta = 1e-5 max |lambda|: what fp32 cannot separate stays the
+// fp32 solver's choice, orthonormalised).  7 n^3 fp64 flops per step on the fp64 matrix cores: 1.5 ms per step at
+// n = 2000, 12 ms at 4096; applied between PMD_SYEVD_F64_MAX (512; below it the whole problem runs in double) and
+// PMD_SYEVD_REFINE_MAX (4096; beyond it the cost reaches the solver's own).  PMD_SYEVD_REFINE_STEPS (2; 0 = off).
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+__global__ void refine_lambda_kernel(const double* __restrict__ S, const double* __restrict__ G, int n, double* __restrict__ lam) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) lam[i] = S[(long)i * n + i] / G[(long)i * n + i];
+}
+// S (column-major, ld n) <- E; lmax = max |lambda~| is taken from the ends of the ascending spectrum
+__global__ void refine_e_kernel(double* __restrict__ S, const double* __restrict__ G, const double* __restrict__ lam, int n) {
+  const int j = blockIdx.y;                                    // column
+  const double lj = lam[j];
+  const double lmax = fmax(fabs(lam[0]), fabs(lam[n - 1]));
+  const double delta = 1e-5 * lmax;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const long k = (long)j * n + i;
+    const double r = (i == j ? 1.0 : 0.0) - G[k];
+    const double dl = lj - lam[i];
+    S[k] = (i != j && fabs(dl) > delta) ? (S[k] + lj * r) / dl : 0.5 * r;
+  }
+}
+__global__ void narrow_vec_kernel(const double* __restrict__ src, float* __restrict__ dst, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = (float)src[i];
+}
+}  // namespace
+
+static int ctx_scratch2(pmd_ctx* ctx, size_t bytes, void** out) {
+  if (ctx->scratch2_bytes < bytes) {
+    PMD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->scratch2) (void)hipFree(ctx->scratch2);
+    ctx->scratch2 = nullptr;
+    ctx->scratch2_bytes = 0;
+    PMD_HIP(ctx, hipMalloc(&ctx->scratch2, bytes));
+    ctx->scratch2_bytes = bytes;
+  }
+  *out = ctx->scratch2;
+  return PMD_OK;
+}
+
+static int refine_steps_for(int n) {
+  static int f64_max = -1, ref_max = -1, steps = -1;
+  if (f64_max < 0) {
+    const char* e0 = getenv("PMD_SYEVD_F64_MAX");
+    const char* e1 = getenv("PMD_SYEVD_REFINE_MAX");
+    const char* e2 = getenv("PMD_SYEVD_REFINE_STEPS");
+    f64_max = e0 ? atoi(e0) : 512;
+    ref_max = e1 ? atoi(e1) : 4096;
+    steps = e2 ? atoi(e2) : 2;
+  }
+  return (n > f64_max && n <= ref_max && steps > 0) ? steps : 0;
+}
+
+// Ad: widened copy of the input matrix (column-major lower triangle valid), taken BEFORE the fp32 solver overwrote A;
+// A (memory row j = eigenvector j) and w are refined in place.  ws: 5 n^2 + n doubles behind Ad.
+static int syevd_refine(pmd_ctx* ctx, int n, const double* Ad, float* A, long lda, float* w, double* ws, int steps) {
+  pmd_prof_scope prof__(ctx, "syevd_refine_f64");
+  const size_t nn = (size_t)n * n;
+  double* X = ws;
+  double* AX = X + nn;
+  double* S = AX + nn;
+  double* G = S + nn;
+  double* Xn = G + nn;
+  double* lam = Xn + nn;
+  const double one = 1.0, zero = 0.0;
+  hipLaunchKernelGGL(widen_kernel, dim3((n + 255) / 256, n), dim3(256), 0, ctx->stream, A, lda, X, (long)n, n);
+  PMD_LAUNCH_CHECK(ctx, "widen_kernel");
+  for (int it = 0; it < steps; ++it) {
+    PMD_BLAS(ctx, rocblas_dsymm(ctx->blas, rocblas_side_left, rocblas_fill_lower, n, n, &one, Ad, n, X, n, &zero, AX, n));
+    PMD_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, n, n, n, &one, X, n, AX, n, &zero, S, n));
+    PMD_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_transpose, rocblas_operation_none, n, n, n, &one, X, n, X, n, &zero, G, n));
+    hipLaunchKernelGGL(refine_lambda_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, S, G, n, lam);
+    hipLaunchKernelGGL(refine_e_kernel, dim3(8, n), dim3(256), 0, ctx->stream, S, G, lam, n);
+    PMD_LAUNCH_CHECK(ctx, "refine_e_kernel");
+    PMD_HIP(ctx, hipMemcpyAsync(Xn, X, nn * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    PMD_BLAS(ctx, rocblas_dgemm(ctx->blas, rocblas_operation_none, rocblas_operation_none, n, n, n, &one, X, n, S, n, &one, Xn, n));
+    double* t = X; X = Xn; Xn = t;
+  }
+  hipLaunchKernelGGL(narrow_kernel, dim3((n + 255) / 256, n), dim3(256), 0, ctx->stream, X, (long)n, A, lda, n);
+  hipLaunchKernelGGL(narrow_vec_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, lam, w, n);
+  PMD_LAUNCH_CHECK(ctx, "narrow_kernel");
+  return PMD_OK;
+}
+
+static int pmd_syevd_f32(pmd_ctx* ctx, int n, float* A, long lda, float* w, float* work, int* info);
+
 // Symmetric eigendecomposition, ascending eigenvalues; on exit memory row j of A is eigenvector j.
 // Only the row-major upper triangle of A (= column-major lower) is read.  work: n floats, info: device int.
 int pmd_syevd(pmd_ctx* ctx, int n, float* A, long lda, float* w, float* work, int* info) {
+  const char* mode0 = getenv("PMD_SYEVD");
+  const int steps = (!mode0 || strcmp(mode0, "f64")) ? refine_steps_for(n) : 0;
+  if (steps == 0) return pmd_syevd_f32(ctx, n, A, lda, w, work, info);
+  void* s2 = nullptr;
+  int rc0 = ctx_scratch2(ctx, (6 * (size_t)n * n + (size_t)n) * sizeof(double) + 4096, &s2);
+  if (rc0 != PMD_OK) return rc0;
+  double* Ad = static_cast<double*>(s2);
+  hipLaunchKernelGGL(widen_kernel, dim3((n + 255) / 256, n), dim3(256), 0, ctx->stream, A, lda, Ad, (long)n, n);
+  PMD_LAUNCH_CHECK(ctx, "widen_kernel");
+  rc0 = pmd_syevd_f32(ctx, n, A, lda, w, work, info);
+  if (rc0 != PMD_OK) return rc0;
+  return syevd_refine(ctx, n, Ad, A, lda, w, Ad + (size_t)n * n, steps);
+}
+
+static int pmd_syevd_f32(pmd_ctx* ctx, int n, float* A, long lda, float* w, float* work, int* info) {
   const char* mode = getenv("PMD_SYEVD");
   const bool force_lib = mode && !strcmp(mode, "rocsolver");
   const bool force_own = mode && !strcmp(mode, "own");

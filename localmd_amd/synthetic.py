@@ -29,7 +29,7 @@ def _sources(d1, d2, T, rng, density=2.0 / 400.0):
     return ci, cj, peak, traces
 
 
-def _ladder_sources(d1, d2, T, n, seed, top=57.0, ratio=0.93):
+def _ladder_sources(d1, d2, T, n, seed, top=57.0, ratio=0.93, smooth=0.0):
     """n bright, spatially separated sources whose singular values form a geometric ladder (ratio between neighbours):
     footprints of sigma 3 px on a jittered grid, zero-mean spike traces scaled to unit RMS, peaks top * ratio^k.  Gives the
     decomposition of a synthetic movie well-separated leading components (parity fixtures: SVD vectors are only
@@ -47,13 +47,21 @@ def _ladder_sources(d1, d2, T, n, seed, top=57.0, ratio=0.93):
     for t in range(T):
         acc = acc * decay + spikes[:, t]
         traces[:, t] = acc
+    if smooth > 0:
+        # band-limited traces instead (white noise smoothed by a Gaussian of `smooth` frames, plain np.convolve): nothing
+        # above ~0.1 cycles / frame, so the Welch noise estimate of the bright pixels stays at the noise level and the
+        # singular values of the standardised movie follow the geometric ladder of the peaks
+        half = int(4 * smooth)
+        ker = np.exp(-0.5 * (np.arange(-half, half + 1) / smooth) ** 2)
+        white = rng.standard_normal((n, T + 2 * half))
+        traces = np.stack([np.convolve(white[k], ker, mode="valid") for k in range(n)])
     traces -= traces.mean(axis=1, keepdims=True)
     traces /= np.sqrt((traces ** 2).mean(axis=1, keepdims=True))
     peak = top * ratio ** np.arange(n)
     return ci, cj, peak, traces.astype(np.float32)
 
 
-def make_movie(T, d1, d2, seed=0, noise=1.0, dtype=np.float32, ladder=0, ladder_top=57.0, ladder_ratio=0.93):
+def make_movie(T, d1, d2, seed=0, noise=1.0, dtype=np.float32, ladder=0, ladder_top=57.0, ladder_ratio=0.93, ladder_smooth=0.0):
     """ladder = n > 0 adds n bright sources with a geometric ladder of singular values (see _ladder_sources); the rest of
     the movie (sources, background, noise draws) is unchanged by it."""
     rng = np.random.Generator(np.random.PCG64(seed))
@@ -71,7 +79,7 @@ def make_movie(T, d1, d2, seed=0, noise=1.0, dtype=np.float32, ladder=0, ladder_
     movie += 100.0
     movie += noise * rng.standard_normal((T, d1, d2), dtype=np.float32)
     if ladder > 0:
-        li, lj, lpeak, ltr = _ladder_sources(d1, d2, T, int(ladder), seed, ladder_top, ladder_ratio)
+        li, lj, lpeak, ltr = _ladder_sources(d1, d2, T, int(ladder), seed, ladder_top, ladder_ratio, ladder_smooth)
         lfoot = np.empty((len(li), d1, d2), dtype=np.float32)
         for n in range(len(li)):
             lfoot[n] = lpeak[n] * np.exp(-((ii - li[n]) ** 2 + (jj - lj[n]) ** 2) / (2 * 3.0 ** 2))

@@ -30,14 +30,14 @@ CASES = {
     # name: movie arguments, decomposition arguments (shared verbatim with the test through the fixture's "case" entry)
     "rle": dict(T=10000, d1=128, d2=128, block=20, movie_seed=5, ladder=24, ladder_top=120.0, ladder_ratio=0.9,
                 max_components=50, seed=321, np_seed=11, sim_iters=20),
-    "headline": dict(T=10000, d1=256, d2=256, block=20, movie_seed=6, ladder=24, ladder_top=120.0, ladder_ratio=0.9,
+    "headline": dict(T=10000, d1=256, d2=256, block=20, movie_seed=6, ladder=28, ladder_top=80.0, ladder_ratio=0.91, ladder_smooth=8.0,
                      max_components=50, seed=654, np_seed=12, sim_iters=20),
 }
 
 
 def case_movie(c):
     return make_movie(c["T"], c["d1"], c["d2"], seed=c["movie_seed"], ladder=c["ladder"], ladder_top=c["ladder_top"],
-                      ladder_ratio=c["ladder_ratio"])
+                      ladder_ratio=c["ladder_ratio"], ladder_smooth=float(c.get("ladder_smooth", 0.0)))
 
 
 def main(name):
