@@ -228,13 +228,16 @@ def main():
     host_rate = None
     if world == 1 and not args.no_host_input and not cfg.get("one_shot"):
         host_movie = movie.cpu().numpy()
-        np.random.seed(0)
-        torch.cuda.synchronize()
-        th = time.perf_counter()
-        localmd_amd.localmd_decomposition(host_movie, (cfg["block"], cfg["block"]), cfg["frames"], max_components=cfg["max_components"],
-                                          seed=seed, ctx=ctx)
-        torch.cuda.synchronize()
-        host_rate = cfg["T"] / (time.perf_counter() - th)
+        # two runs, the second one timed: the first also page-locks the ring of staging buffers, which the library keeps
+        # between calls (0.25 s of a cold 1.19 s at config 3; the steady state of a process that decomposes movie after movie)
+        for rep in range(2):
+            np.random.seed(0)
+            torch.cuda.synchronize()
+            th = time.perf_counter()
+            localmd_amd.localmd_decomposition(host_movie, (cfg["block"], cfg["block"]), cfg["frames"], max_components=cfg["max_components"],
+                                              seed=seed, ctx=ctx)
+            torch.cuda.synchronize()
+            host_rate = cfg["T"] / (time.perf_counter() - th)
         del host_movie
     ms_per_step = 1e3 * elapsed / args.steps
     # N ranks decompose ONE movie together (tile grid sharded, results gathered): total work is fixed

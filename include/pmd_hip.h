@@ -125,7 +125,7 @@ int pmd_tiles_hook_offsets(int n_tiles, int b1, int b2, int P, int r, int a, int
                            size_t* vds_offset, size_t* s_offset);
 
 /* A9: one further temporal window (decomposition.py:333-387 single_residual_block_md, :489-515): xw = the
- * window's frames (pixel-major, L frames); Ucur[n][64][dpad] holds counts[tile] components (other rows zero)
+ * window's frames (pixel-major, L frames); Ucur[n][rp][dpad] (rp = pmd_tile_rpad(r)) holds counts[tile] components (other rows zero)
  * and receives the kept components of the residual fit; counts is updated.  pmd_tiles_truncate clears the
  * rows >= counts[tile] of a basis array (after the first window). */
 size_t pmd_tiles_residual_workspace_bytes(int n_tiles, int b1, int b2, int r, int a, int L, long n_rows);
@@ -133,7 +133,7 @@ int pmd_tiles_residual(pmd_ctx* ctx, const float* xw, long ldx, long n_rows, int
                        int b1, int b2, int r, int a, float thr_s, float thr_t, int max_fail, uint64_t seed,
                        uint32_t omega_index0, uint32_t omega_index_step, float* Ucur, int* counts, float* stats_out,
                        int* good_out, int* keep_out, void* ws, size_t ws_bytes);
-int pmd_tiles_truncate(pmd_ctx* ctx, float* U, int dpad, const int* counts, int n_tiles);
+int pmd_tiles_truncate(pmd_ctx* ctx, float* U, int dpad, const int* counts, int n_tiles, int rpad);
 
 /* A13: weight and normalise tile bases: Uw = Ut * w[q] / cumw[pix]  (decomposition.py:812-853). */
 int pmd_weight_tiles(pmd_ctx* ctx, const float* Ut, int dpad, const int* tile_pix, int d, const float* w,

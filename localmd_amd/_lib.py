@@ -56,7 +56,7 @@ SIGNATURES = {
     "pmd_tiles_residual_workspace_bytes": (c_sz, [c_i, c_i, c_i, c_i, c_i, c_i, c_l]),
     "pmd_tiles_residual": (c_i, [c_p, c_p, c_l, c_l, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_i, c_u64, c_u32, c_u32,
                                  c_p, c_p, c_p, c_p, c_p, c_p, c_sz]),
-    "pmd_tiles_truncate": (c_i, [c_p, c_p, c_i, c_p, c_i]),
+    "pmd_tiles_truncate": (c_i, [c_p, c_p, c_i, c_p, c_i, c_i]),
     "pmd_weight_tiles": (c_i, [c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_i]),
     "pmd_tiles_project": (c_i, [c_p, c_p, c_l, c_i, c_p, c_i, c_i, c_p, c_i, c_p, c_l, c_i]),
     "pmd_compact_rows": (c_i, [c_p, c_p, c_l, c_p, c_p, c_i, c_p, c_l, c_i]),

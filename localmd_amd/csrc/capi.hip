@@ -246,9 +246,10 @@ int pmd_tiles_residual(pmd_ctx* ctx, const float* xw, long ldx, long n_rows, int
   return pmd_tiles_residual_impl(ctx, xw, ldx, n_rows, L, tile_pix, n_tiles, b1, b2, r, a, thr_s, thr_t, max_fail, seed,
                                  omega_index0, omega_index_step, Ucur, counts, stats_out, good_out, keep_out, ws, ws_bytes);
 }
-int pmd_tiles_truncate(pmd_ctx* ctx, float* U, int dpad, const int* counts, int n_tiles) {
+int pmd_tiles_truncate(pmd_ctx* ctx, float* U, int dpad, const int* counts, int n_tiles, int rpad) {
   CTX_CHECK(ctx);
-  return pmd_launch_tile_truncate(ctx, U, dpad, counts, n_tiles);
+  if (rpad < 64 || rpad % 64) return pmd_fail(ctx, PMD_ERR_ARG, "pmd_tiles_truncate", "rpad must be a positive multiple of 64");
+  return pmd_launch_tile_truncate(ctx, U, dpad, counts, n_tiles, rpad);
 }
 
 int pmd_weight_tiles(pmd_ctx* ctx, const float* Ut, int dpad, const int* tile_pix, int d, const float* w,

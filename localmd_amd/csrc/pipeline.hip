@@ -100,10 +100,18 @@ size_t pmd_tiles_workspace_bytes_impl(int n, int d, int P, int r, int a, int t_c
   return ar.used + 4096;
 }
 
+// scratch of the generic-width small-matrix steps
+struct wide_ws {
+  int rp;
+  double *gpart, *nmat, *lam;
+  void* eig_ws;
+  size_t eig_ws_bytes;
+};
+
 // Orthonormal basis of the row space of a [comp][x] array by two rounds of Gram matrix -> eigen-whitening (E Lambda^-1/2,
 // null directions zeroed) -> row mixing: the generic-width counterpart of CholeskyQR2 / small_qr.  Any orthonormal basis
 // of the sketch's span serves the rSVD (B = Q^T A, U = Q u are invariant under Q -> Q O).
-static int wide_orthonormalise(pmd_ctx* ctx, const tiles_plan& p, const float* src, long stride, long ld, int len, int n_in, int n_out,
+static int wide_orthonormalise(pmd_ctx* ctx, const wide_ws& p, const float* src, long stride, long ld, int len, int n_in, int n_out,
                                float* dst, int n) {
   for (int pass = 0; pass < 2; ++pass) {
     RUN(pmd_launch_wide_gram(ctx, src, stride, ld, len, n, 1, p.rp, p.gpart));
@@ -134,7 +142,8 @@ static int tiles_decompose_wide(pmd_ctx* ctx, const tiles_plan& p, const float* 
                          p.l, 1, p.omT + (long)t0 * srb, p.ld_b, srb));
     }
     RUN(pmd_launch_tile_xbt_rp(ctx, p.abar, p.ld_b, nullptr, 0, P, P, p.omT, srb, p.ld_b, p.yt, srP, 0, p.Ppad, n, p.nb, 1, p.l));
-    RUN(wide_orthonormalise(ctx, p, p.yt, srP, p.Ppad, P, p.l, p.nref, p.qt, n));
+    const wide_ws wws = {p.rp, p.gpart, p.nmat, p.lam, p.eig_ws, p.eig_ws_bytes};
+    RUN(wide_orthonormalise(ctx, wws, p.yt, srP, p.Ppad, P, p.l, p.nref, p.qt, n));
     RUN(pmd_launch_tile_atx_rp(ctx, p.abar, p.ld_b, nullptr, 0, P, P, p.qt, srP, p.Ppad, p.bm, srb, p.ld_b, n, p.nb, 1, p.nref));
     RUN(pmd_launch_wide_gram(ctx, p.bm, srb, p.ld_b, p.nb, n, 1, rp, p.gpart));
     RUN(pmd_launch_wide_eig(ctx, p.gpart, 1, rp, p.nref, 0, 0.0, p.nmat, p.lam, n, p.eig_ws, p.eig_ws_bytes));
@@ -197,6 +206,11 @@ int pmd_tiles_decompose_impl(pmd_ctx* ctx, const float* Xf, long ldx, long n_row
   if (whiten_mode < 0) { const char* e = getenv("PMD_TILE_WHITEN"); whiten_mode = (e && !strcmp(e, "eig")) ? 0 : 1; }
   const bool whiten_chol = whiten_mode && stages == 7;   // the spatial_denoiser hook sees S = X V_b^T column by column
   const bool whiten_chol_u0 = whiten_mode != 0;
+  // Time slices of the two contractions over all frames: four per tile give a few thousand tiles enough workgroups to fill
+  // the chip; with many tiles (the 16 x 16-pixel regime: 16 129 / 65 025 tiles) one slice does, and the partial results
+  // and their reduction pass (10 of 300 ms at 1024 x 1024 x 1000, b = 16) disappear.
+  const int xs = n >= 4096 ? 1 : XBT_SLICES;
+  const int gs = n >= 4096 ? 1 : GRAM_SLICES;
 
   // stages: bit 0 = up to V_ds (p.outA; the temporal_denoiser hook of decomposition.py:300 acts on it),
   //         bit 1 = basis of its row space and S = X V_b^T (p.sst; spatial_denoiser hook, :310), bit 2 = the rest
@@ -226,16 +240,20 @@ int pmd_tiles_decompose_impl(pmd_ctx* ctx, const float* Xf, long ldx, long n_row
   }
   if (stages & 2) {
   // (this Gram only conditions the basis change -- span(S) does not depend on it -- so fp32 MFMA is enough)
-  RUN(pmd_launch_tile_xbt(ctx, p.outA, ldv, nullptr, 0, 64, 64, p.outA, s64v, ldv, p.g1f, GRAM_SLICES * 4096L, 4096, 64, n, t_crop, GRAM_SLICES));
-  RUN(pmd_launch_gram_f2d(ctx, p.g1f, 64, (long)n * GRAM_SLICES, p.gpart));
+  RUN(pmd_launch_tile_xbt(ctx, p.outA, ldv, nullptr, 0, 64, 64, p.outA, s64v, ldv, p.g1f, gs * 4096L, 4096, 64, n, t_crop, gs));
+  RUN(pmd_launch_gram_f2d(ctx, p.g1f, 64, (long)n * gs, p.gpart));
   // only span(S) matters downstream: with no denoiser hook reading S component by component (stages == 7) any orthonormal
   // basis of the row space of V_ds serves, and the Cholesky whitening replaces the Jacobi eigensolver (small_la.hip)
-  if (whiten_chol) RUN(pmd_launch_small_chol(ctx, p.gpart, GRAM_SLICES, r, 1e-10, p.nmat, n));
-  else RUN(pmd_launch_small_eig(ctx, p.gpart, GRAM_SLICES, r, 1, 1e-10, p.nmat, p.lam, n));
+  if (whiten_chol) RUN(pmd_launch_small_chol(ctx, p.gpart, gs, r, 1e-10, p.nmat, n));
+  else RUN(pmd_launch_small_eig(ctx, p.gpart, gs, r, 1, 1e-10, p.nmat, p.lam, n));
 
   // --- S = X V_b^T and its left singular vectors U0 (decomposition.py:304-317)
-  RUN(pmd_launch_tile_xbt(ctx, Xf, ldx, tile_pix, d, 0, d, p.outA, s64v, ldv, p.spart, XBT_SLICES * s64d, s64d, p.dpad, n, t_crop, XBT_SLICES));
-  RUN(pmd_launch_reduce_slices(ctx, p.spart, XBT_SLICES * s64d, s64d, XBT_SLICES, s64d, p.sst, s64d, n));
+  if (xs == 1) {
+    RUN(pmd_launch_tile_xbt(ctx, Xf, ldx, tile_pix, d, 0, d, p.outA, s64v, ldv, p.sst, s64d, 0, p.dpad, n, t_crop, 1));
+  } else {
+    RUN(pmd_launch_tile_xbt(ctx, Xf, ldx, tile_pix, d, 0, d, p.outA, s64v, ldv, p.spart, XBT_SLICES * s64d, s64d, p.dpad, n, t_crop, XBT_SLICES));
+    RUN(pmd_launch_reduce_slices(ctx, p.spart, XBT_SLICES * s64d, s64d, XBT_SLICES, s64d, p.sst, s64d, n));
+  }
   RUN(pmd_launch_tile_rowmix(ctx, p.sst, s64d, p.dpad, p.nmat, 4096, r, r, p.sst, s64d, p.dpad, d, n));
   }
   if (stages & 4) {
@@ -249,8 +267,8 @@ int pmd_tiles_decompose_impl(pmd_ctx* ctx, const float* Xf, long ldx, long n_row
   ctx->atx_label = "tile_atx_main";
   RUN(pmd_launch_tile_atx(ctx, Xf, ldx, tile_pix, d, 0, d, p.sst, s64d, p.dpad, V_out, s64v, ldv, n, t_crop, 2));
   ctx->atx_label = nullptr;
-  RUN(pmd_launch_tile_gram(ctx, V_out, s64v, ldv, t_crop, n, GRAM_SLICES, p.gpart));
-  RUN(pmd_launch_small_eig(ctx, p.gpart, GRAM_SLICES, r, 0, 0.0, p.nmat, sing_out ? sing_out : p.lam, n));
+  RUN(pmd_launch_tile_gram(ctx, V_out, s64v, ldv, t_crop, n, gs, p.gpart));
+  RUN(pmd_launch_small_eig(ctx, p.gpart, gs, r, 0, 0.0, p.nmat, sing_out ? sing_out : p.lam, n));
   RUN(pmd_launch_tile_rowmix(ctx, p.sst, s64d, p.dpad, p.nmat, 4096, r, r, Ut_out, s64d, p.dpad, d, n));
   RUN(pmd_launch_tile_rowmix(ctx, V_out, s64v, ldv, p.nmat, 4096, r, r, V_out, s64v, ldv, t_crop, n));
 
@@ -277,36 +295,46 @@ int pmd_tiles_hook_offsets_impl(int n, int d, int P, int r, int a, int t_crop, l
 // temporal bin average, so the residual is never materialised at full resolution.
 // ------------------------------------------------------------------------------------------
 struct resid_plan {
-  int nb, l, dpad, nref;
+  int nb, l, dpad, nref, rp;
   long ld_b, ld_L;
   float *xbar, *wbar, *ar, *omT, *yt, *qt, *bm, *unew, *tmp, *util, *vmat;
   double *gpart, *nmat, *lam;
+  void* eig_ws;
+  size_t eig_ws_bytes;
   size_t zero_bytes;
 };
 
 static int plan_resid(pmd_arena& ar, resid_plan& p, int n, int d, int r, int a, int L, long n_rows) {
   p.nb = L / a;
   p.l = r + 10;
+  p.rp = pmd_tile_rpad(r);
+  const size_t rp = p.rp, rp2 = rp * rp;
   p.dpad = pmd_tile_dpad(d);
   if (p.dpad < 0) return PMD_ERR_UNSUPPORTED;
   p.nref = d < p.l ? d : p.l;
   p.ld_b = pmd_time_ld(p.nb);
   p.ld_L = pmd_time_ld(L);
-  p.omT = ar.take_n<float>((size_t)n * 64 * p.ld_b);
+  p.omT = ar.take_n<float>((size_t)n * rp * p.ld_b);
   p.ar = ar.take_n<float>((size_t)n * d * p.ld_b);
-  p.yt = ar.take_n<float>((size_t)n * 64 * p.dpad);
-  p.qt = ar.take_n<float>((size_t)n * 64 * p.dpad);
-  p.unew = ar.take_n<float>((size_t)n * 64 * p.dpad);
-  p.tmp = ar.take_n<float>((size_t)n * 64 * p.dpad);
-  p.util = ar.take_n<float>((size_t)n * 64 * p.dpad);
+  p.yt = ar.take_n<float>((size_t)n * rp * p.dpad);
+  p.qt = ar.take_n<float>((size_t)n * rp * p.dpad);
+  p.unew = ar.take_n<float>((size_t)n * rp * p.dpad);
+  p.tmp = ar.take_n<float>((size_t)n * rp * p.dpad);
+  p.util = ar.take_n<float>((size_t)n * rp * p.dpad);
   p.zero_bytes = ar.used;
   p.xbar = ar.take_n<float>((size_t)n_rows * p.ld_b);
-  p.wbar = ar.take_n<float>((size_t)n * 64 * p.ld_b);
-  p.bm = ar.take_n<float>((size_t)n * 64 * p.ld_b);
-  p.vmat = ar.take_n<float>((size_t)n * 64 * p.ld_L);
-  p.gpart = ar.take_n<double>((size_t)n * GRAM_SLICES * 4096);
-  p.nmat = ar.take_n<double>((size_t)n * 4096);
-  p.lam = ar.take_n<double>((size_t)n * 64);
+  p.wbar = ar.take_n<float>((size_t)n * rp * p.ld_b);
+  p.bm = ar.take_n<float>((size_t)n * rp * p.ld_b);
+  p.vmat = ar.take_n<float>((size_t)n * rp * p.ld_L);
+  p.gpart = ar.take_n<double>((size_t)n * GRAM_SLICES * rp2);
+  p.nmat = ar.take_n<double>((size_t)n * rp2);
+  p.lam = ar.take_n<double>((size_t)n * rp);
+  p.eig_ws = nullptr;
+  p.eig_ws_bytes = 0;
+  if (p.rp > 64) {
+    p.eig_ws_bytes = pmd_wide_eig_workspace_bytes(p.rp, n);
+    p.eig_ws = ar.take(p.eig_ws_bytes);
+  }
   return PMD_OK;
 }
 
@@ -322,13 +350,44 @@ int pmd_tiles_residual_impl(pmd_ctx* ctx, const float* Xw, long ldx, long n_rows
                             uint32_t omega_index0, uint32_t omega_index_step, float* Ucur, int* counts, float* stats_out,
                             int* good_out, int* keep_out, void* ws, size_t ws_bytes) {
   const int d = b1 * b2;
-  if (r < 1 || r + 10 > 64) return pmd_fail(ctx, PMD_ERR_UNSUPPORTED, "pmd_tiles_residual", "max_components must be in [1, 54]");
+  if (r < 1) return pmd_fail(ctx, PMD_ERR_ARG, "pmd_tiles_residual", "max_components must be >= 1");
   if (a < 1 || L % a != 0 || L / a < 1) return pmd_fail(ctx, PMD_ERR_ARG, "pmd_tiles_residual", "window length must be a positive multiple of temporal_avg_factor");
   if (ldx < pmd_time_ld(L)) return pmd_fail(ctx, PMD_ERR_ARG, "pmd_tiles_residual", "leading dimension too small");
   pmd_arena ar(ws, ws_bytes);
   resid_plan p;
   if (plan_resid(ar, p, n, d, r, a, L, n_rows) != PMD_OK) return pmd_fail(ctx, PMD_ERR_UNSUPPORTED, "pmd_tiles_residual", "tile too large");
   if (ar.overflow) return pmd_fail(ctx, PMD_ERR_WORKSPACE, "pmd_tiles_residual", "workspace too small");
+  if (p.rp > 64) {
+    // generic-width form (max_components + 10 > 64): the same sequence through wide.hip and row blocks of 64
+    const int rp = p.rp;
+    const long srd = (long)rp * p.dpad, srb = (long)rp * p.ld_b, srL = (long)rp * p.ld_L, rp2 = (long)rp * rp;
+    const wide_ws wws = {rp, p.gpart, p.nmat, p.lam, p.eig_ws, p.eig_ws_bytes};
+    PMD_HIP(ctx, hipMemsetAsync(ws, 0, p.zero_bytes, ctx->stream));
+    RUN(pmd_launch_bin_average(ctx, Xw, ldx, n_rows, a, p.nb, p.xbar, p.ld_b));
+    RUN(pmd_launch_tile_atx_rp(ctx, p.xbar, p.ld_b, tile_pix, d, 0, d, Ucur, srd, p.dpad, p.wbar, srb, p.ld_b, n, p.nb, 1, r));
+    RUN(pmd_launch_tile_residual_rows(ctx, p.xbar, p.ld_b, tile_pix, d, Ucur, p.dpad, p.wbar, p.ld_b, r, p.nb, p.ar, p.ld_b, n, rp));
+    for (int t0 = 0; t0 < n; t0 += 32768) {
+      const int tn = (n - t0 < 32768) ? n - t0 : 32768;
+      RUN(pmd_launch_rng(ctx, seed, PMD_STREAM_TILE_OMEGA, omega_index0 + (uint32_t)t0 * omega_index_step, omega_index_step, tn, p.nb, p.l, 1,
+                         p.omT + (long)t0 * srb, p.ld_b, srb));
+    }
+    RUN(pmd_launch_tile_xbt_rp(ctx, p.ar, p.ld_b, nullptr, 0, d, d, p.omT, srb, p.ld_b, p.yt, srd, 0, p.dpad, n, p.nb, 1, p.l));
+    RUN(wide_orthonormalise(ctx, wws, p.yt, srd, p.dpad, d, p.l, p.nref, p.qt, n));
+    RUN(pmd_launch_tile_atx_rp(ctx, p.ar, p.ld_b, nullptr, 0, d, d, p.qt, srd, p.dpad, p.bm, srb, p.ld_b, n, p.nb, 1, p.nref));
+    RUN(pmd_launch_wide_gram(ctx, p.bm, srb, p.ld_b, p.nb, n, 1, rp, p.gpart));
+    RUN(pmd_launch_wide_eig(ctx, p.gpart, 1, rp, p.nref, 0, 0.0, p.nmat, p.lam, n, p.eig_ws, p.eig_ws_bytes));
+    const int rnw = std::min(r, std::min(p.nb, p.nref));
+    RUN(pmd_launch_wide_rowmix(ctx, p.qt, srd, p.dpad, p.nmat, rp2, rp, p.nref, rnw, p.unew, srd, p.dpad, d, n));
+    // utilde = u - E (E^T u): the cross Gram matrix E^T u is the mixing matrix of the row mix of E
+    RUN(pmd_launch_wide_gram(ctx, Ucur, srd, p.dpad, d, n, 1, rp, p.nmat, p.unew));
+    RUN(pmd_launch_wide_rowmix(ctx, Ucur, srd, p.dpad, p.nmat, rp2, rp, r, rnw, p.tmp, srd, p.dpad, d, n));
+    PMD_HIP(ctx, hipMemcpyAsync(p.util, p.unew, (size_t)n * srd * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    RUN(pmd_launch_tile_sub(ctx, p.util, p.tmp, srd, p.dpad, d, n, rp));
+    RUN(pmd_launch_tile_atx_rp(ctx, Xw, ldx, tile_pix, d, 0, d, p.util, srd, p.dpad, p.vmat, srL, p.ld_L, n, L, 2, rnw));
+    RUN(pmd_launch_stats_roughness(ctx, p.unew, srd, p.dpad, b1, b2, p.vmat, srL, p.ld_L, L, rnw, stats_out, n, rp));
+    RUN(pmd_launch_tile_append(ctx, stats_out, rnw, thr_s, thr_t, max_fail, r, p.unew, Ucur, p.dpad, counts, good_out, keep_out, n, rp));
+    return PMD_OK;
+  }
   const long s64d = 64L * p.dpad, s64b = 64L * p.ld_b, s64L = 64L * p.ld_L;
   PMD_HIP(ctx, hipMemsetAsync(ws, 0, p.zero_bytes, ctx->stream));
 

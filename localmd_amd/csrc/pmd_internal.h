@@ -60,7 +60,7 @@ int pmd_launch_decide(pmd_ctx* ctx, const float* stats, int r, float thr_s, floa
 // wide.hip: generic-width forms (per-tile arrays [tile][rp][x], rp = pmd_tile_rpad(r) > 64)
 extern "C" int pmd_tile_rpad(int r);
 int pmd_launch_wide_gram(pmd_ctx* ctx, const float* In, long tile_stride, long ld, int len, int n_tiles, int slices, int rp,
-                         double* G);
+                         double* G, const float* In2 = nullptr);
 size_t pmd_wide_eig_workspace_bytes(int n, int n_tiles);
 int pmd_launch_wide_eig(pmd_ctx* ctx, const double* G, int slices, int rp, int n, int mode, double tol, double* Nout,
                         double* lam_out, int n_tiles, void* ws, size_t ws_bytes);
@@ -179,11 +179,12 @@ int pmd_launch_tile_cross_gram(pmd_ctx* ctx, const float* A, const float* B, lon
                                double* G, int n_tiles);
 int pmd_launch_tile_residual_rows(pmd_ctx* ctx, const float* X, long ldx, const int* pix, int d, const float* E,
                                   int e_ld, const float* W, long w_ld, int r, int len, float* out, long out_ld,
-                                  int n_tiles);
-int pmd_launch_tile_sub(pmd_ctx* ctx, float* a, const float* b, long tile_stride, int ld, int len, int n_tiles);
+                                  int n_tiles, int rp = PMD_RPAD);
+int pmd_launch_tile_sub(pmd_ctx* ctx, float* a, const float* b, long tile_stride, int ld, int len, int n_tiles, int rp = PMD_RPAD);
 int pmd_launch_tile_append(pmd_ctx* ctx, const float* stats, int r, float thr_s, float thr_t, int max_fail, int cap,
-                           const float* Unew, float* Ucur, int ld, int* counts, int* good, int* keep, int n_tiles);
-int pmd_launch_tile_truncate(pmd_ctx* ctx, float* U, int ld, const int* counts, int n_tiles);
+                           const float* Unew, float* Ucur, int ld, int* counts, int* good, int* keep, int n_tiles,
+                           int rp = PMD_RPAD);
+int pmd_launch_tile_truncate(pmd_ctx* ctx, float* U, int ld, const int* counts, int n_tiles, int rp = PMD_RPAD);
 size_t pmd_tiles_residual_workspace_bytes_impl(int n, int d, int r, int a, int L, long n_rows);
 int pmd_tiles_residual_impl(pmd_ctx* ctx, const float* Xw, long ldx, long n_rows, int L, const int* tile_pix, int n,
                             int b1, int b2, int r, int a, float thr_s, float thr_t, int max_fail, uint64_t seed,

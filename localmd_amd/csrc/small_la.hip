@@ -5,7 +5,7 @@
 //                with the streaming Gram/rowmix kernels it replaces the jnp.linalg.svd calls at
 //                decomposition.py:66, :301, :315-317, :319 (SVD of M as eigh(M M^T))
 //   roughness statistics and the keep/discard scan (evaluation.py:84-126, :133-222)
-#include "pmd_common.h"
+#include "pmd_internal.h"
 
 // ---------------------------------------------------------------- Householder QR ----------
 // Yt: [tile][comp][q] (fp32), P rows (q < P), l columns (comp < l).  Qt out: [tile][comp][q],
@@ -271,6 +271,23 @@ int pmd_launch_small_eig(pmd_ctx* ctx, const double* G, int slices, int n, int m
   pmd_prof_scope prof__(ctx, "small_eig");
   if (n_tiles <= 0) return PMD_OK;
   if (n > 64 || n < 1) return pmd_fail(ctx, PMD_ERR_UNSUPPORTED, "small_eig", "n must be in [1, 64]");
+  {
+    // A/B: PMD_SMALL_EIG=rocsolver routes the batch through rocSOLVER's strided-batched dsyevd (wide.hip, rp = 64)
+    static int lib_mode = -1;
+    if (lib_mode < 0) { const char* e = getenv("PMD_SMALL_EIG"); lib_mode = (e && !strcmp(e, "rocsolver")) ? 1 : 0; }
+    if (lib_mode) {
+      const size_t need = pmd_wide_eig_workspace_bytes(64, n_tiles);
+      if (ctx->scratch2_bytes < need) {
+        PMD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->scratch2) (void)hipFree(ctx->scratch2);
+        ctx->scratch2 = nullptr;
+        ctx->scratch2_bytes = 0;
+        PMD_HIP(ctx, hipMalloc(&ctx->scratch2, need));
+        ctx->scratch2_bytes = need;
+      }
+      return pmd_launch_wide_eig(ctx, G, slices, 64, n, mode, tol, Nout, lam_out, n_tiles, ctx->scratch2, ctx->scratch2_bytes);
+    }
+  }
   const size_t bytes = (size_t)2 * 64 * EIG_LD * sizeof(double) + 64 * sizeof(double) + (64 + 2 + 64) * sizeof(int) + 64;
   static int threads = 0;
   if (!threads) {
@@ -558,10 +575,10 @@ __global__ __launch_bounds__(256) void tile_residual_rows_kernel(const float* __
                                                                  const int* __restrict__ pix, int d,
                                                                  const float* __restrict__ E, int e_ld,
                                                                  const float* __restrict__ W, long w_ld, int r, int len,
-                                                                 float* __restrict__ out, long out_ld) {
+                                                                 float* __restrict__ out, long out_ld, int rp) {
   const int tile = blockIdx.z, q = blockIdx.y;
-  const float* e = E + (long)tile * 64 * e_ld + q;
-  const float* w = W + (long)tile * 64 * w_ld;
+  const float* e = E + (long)tile * rp * e_ld + q;
+  const float* w = W + (long)tile * rp * w_ld;
   const float* xr = X + (long)pix[(long)tile * d + q] * ldx;
   for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < len; x += gridDim.x * blockDim.x) {
     float acc = 0.f;
@@ -572,7 +589,7 @@ __global__ __launch_bounds__(256) void tile_residual_rows_kernel(const float* __
 
 int pmd_launch_tile_residual_rows(pmd_ctx* ctx, const float* X, long ldx, const int* pix, int d, const float* E,
                                   int e_ld, const float* W, long w_ld, int r, int len, float* out, long out_ld,
-                                  int n_tiles) {
+                                  int n_tiles, int rp) {
   pmd_prof_scope prof__(ctx, "tile_residual_rows");
   if (n_tiles <= 0) return PMD_OK;
   int bx = (len + 255) / 256;
@@ -580,27 +597,27 @@ int pmd_launch_tile_residual_rows(pmd_ctx* ctx, const float* X, long ldx, const 
   for (int t0 = 0; t0 < n_tiles; t0 += 32768) {
     const int tn = (n_tiles - t0 < 32768) ? n_tiles - t0 : 32768;
     hipLaunchKernelGGL(tile_residual_rows_kernel, dim3(bx, d, tn), dim3(256), 0, ctx->stream, X, ldx, pix + (long)t0 * d, d,
-                       E + (long)t0 * 64 * e_ld, e_ld, W + (long)t0 * 64 * w_ld, w_ld, r, len,
-                       out + (long)t0 * d * out_ld, out_ld);
+                       E + (long)t0 * rp * e_ld, e_ld, W + (long)t0 * rp * w_ld, w_ld, r, len,
+                       out + (long)t0 * d * out_ld, out_ld, rp);
     PMD_LAUNCH_CHECK(ctx, "tile_residual_rows_kernel");
   }
   return PMD_OK;
 }
 
 // a[tile][c][x] -= b[tile][c][x]   (c < 64, x < len)
-__global__ void tile_sub_kernel(float* __restrict__ a, const float* __restrict__ b, long tile_stride, int ld, int len) {
+__global__ void tile_sub_kernel(float* __restrict__ a, const float* __restrict__ b, long tile_stride, int ld, int len, int rp) {
   const int tile = blockIdx.y;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 64 * len; i += gridDim.x * blockDim.x) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rp * len; i += gridDim.x * blockDim.x) {
     const int c = i / len, x = i - c * len;
     a[(long)tile * tile_stride + (long)c * ld + x] -= b[(long)tile * tile_stride + (long)c * ld + x];
   }
 }
 
-int pmd_launch_tile_sub(pmd_ctx* ctx, float* a, const float* b, long tile_stride, int ld, int len, int n_tiles) {
+int pmd_launch_tile_sub(pmd_ctx* ctx, float* a, const float* b, long tile_stride, int ld, int len, int n_tiles, int rp) {
   for (int t0 = 0; t0 < n_tiles; t0 += 32768) {
     const int tn = (n_tiles - t0 < 32768) ? n_tiles - t0 : 32768;
     hipLaunchKernelGGL(tile_sub_kernel, dim3(16, tn), dim3(256), 0, ctx->stream, a + (long)t0 * tile_stride,
-                       b + (long)t0 * tile_stride, tile_stride, ld, len);
+                       b + (long)t0 * tile_stride, tile_stride, ld, len, rp);
     PMD_LAUNCH_CHECK(ctx, "tile_sub_kernel");
   }
   return PMD_OK;
@@ -612,25 +629,25 @@ __global__ __launch_bounds__(256) void tile_append_kernel(const float* __restric
                                                           float thr_t, int max_fail, int cap,
                                                           const float* __restrict__ Unew, float* __restrict__ Ucur,
                                                           int ld, int* __restrict__ counts, int* __restrict__ good,
-                                                          int* __restrict__ keep) {
+                                                          int* __restrict__ keep, int rp) {
   __shared__ int s_take, s_base;
   const int tile = blockIdx.x;
   if (threadIdx.x == 0) {
     int fails = 0, kept = 0;
     bool all_fails = false;
-    for (int c = 0; c < PMD_RPAD; ++c) {
+    for (int c = 0; c < rp; ++c) {
       int g = 0, k = 0;
       if (c < r) {
-        const float sp = stats[((long)tile * PMD_RPAD + c) * 2 + 0];
-        const float tp = stats[((long)tile * PMD_RPAD + c) * 2 + 1];
+        const float sp = stats[((long)tile * rp + c) * 2 + 0];
+        const float tp = stats[((long)tile * rp + c) * 2 + 1];
         g = (sp < thr_s) && (tp < thr_t);
         if (all_fails) k = 0;
         else if (!g) { fails++; k = 1; if (fails == max_fail) all_fails = true; }
         else { fails = 0; k = 1; }
         kept += k;
       }
-      good[(long)tile * PMD_RPAD + c] = g;
-      keep[(long)tile * PMD_RPAD + c] = k;
+      good[(long)tile * rp + c] = g;
+      keep[(long)tile * rp + c] = k;
     }
     const int base = counts[tile];
     const int remaining = cap - base;
@@ -642,31 +659,31 @@ __global__ __launch_bounds__(256) void tile_append_kernel(const float* __restric
   const int take = s_take, base = s_base;
   for (int i = threadIdx.x; i < take * ld; i += 256) {
     const int c = i / ld, x = i - c * ld;
-    Ucur[(long)tile * 64 * ld + (long)(base + c) * ld + x] = Unew[(long)tile * 64 * ld + (long)c * ld + x];
+    Ucur[(long)tile * rp * ld + (long)(base + c) * ld + x] = Unew[(long)tile * rp * ld + (long)c * ld + x];
   }
 }
 
 int pmd_launch_tile_append(pmd_ctx* ctx, const float* stats, int r, float thr_s, float thr_t, int max_fail, int cap,
-                           const float* Unew, float* Ucur, int ld, int* counts, int* good, int* keep, int n_tiles) {
+                           const float* Unew, float* Ucur, int ld, int* counts, int* good, int* keep, int n_tiles, int rp) {
   if (n_tiles <= 0) return PMD_OK;
   hipLaunchKernelGGL(tile_append_kernel, dim3(n_tiles), dim3(256), 0, ctx->stream, stats, r, thr_s, thr_t, max_fail, cap,
-                     Unew, Ucur, ld, counts, good, keep);
+                     Unew, Ucur, ld, counts, good, keep, rp);
   PMD_LAUNCH_CHECK(ctx, "tile_append_kernel");
   return PMD_OK;
 }
 
 // rows c >= counts[tile] of U[tile][c][:] are cleared (components that were not kept)
-__global__ void tile_truncate_kernel(float* __restrict__ U, int ld, const int* __restrict__ counts) {
+__global__ void tile_truncate_kernel(float* __restrict__ U, int ld, const int* __restrict__ counts, int rp) {
   const int tile = blockIdx.y;
   const int k = counts[tile];
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < (PMD_RPAD - k) * ld; i += gridDim.x * blockDim.x)
-    U[(long)tile * 64 * ld + (long)k * ld + i] = 0.f;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < (rp - k) * ld; i += gridDim.x * blockDim.x)
+    U[(long)tile * rp * ld + (long)k * ld + i] = 0.f;
 }
 
-int pmd_launch_tile_truncate(pmd_ctx* ctx, float* U, int ld, const int* counts, int n_tiles) {
+int pmd_launch_tile_truncate(pmd_ctx* ctx, float* U, int ld, const int* counts, int n_tiles, int rp) {
   for (int t0 = 0; t0 < n_tiles; t0 += 32768) {
     const int tn = (n_tiles - t0 < 32768) ? n_tiles - t0 : 32768;
-    hipLaunchKernelGGL(tile_truncate_kernel, dim3(16, tn), dim3(256), 0, ctx->stream, U + (long)t0 * 64 * ld, ld, counts + t0);
+    hipLaunchKernelGGL(tile_truncate_kernel, dim3(16, tn), dim3(256), 0, ctx->stream, U + (long)t0 * rp * ld, ld, counts + t0, rp);
     PMD_LAUNCH_CHECK(ctx, "tile_truncate_kernel");
   }
   return PMD_OK;

@@ -667,7 +667,16 @@ __global__ __launch_bounds__(256) void reduce_slices4_kernel(const float4* __res
     s2 = (double)a.z + (double)b.z + (double)c.z + (double)d.z;
     s3 = (double)a.w + (double)b.w + (double)c.w + (double)d.w;
   } else {
-    for (int k = 0; k < slices; ++k) {
+    // many slices (the background projection sums one partial per block of 1024 pixels): eight loads in flight per thread
+    int k = 0;
+    for (; k + 8 <= slices; k += 8) {
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[(long)(k + u) * slice_stride4];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s0 += (double)v[u].x; s1 += (double)v[u].y; s2 += (double)v[u].z; s3 += (double)v[u].w; }
+    }
+    for (; k < slices; ++k) {
       const float4 v = src[(long)k * slice_stride4];
       s0 += (double)v.x; s1 += (double)v.y; s2 += (double)v.z; s3 += (double)v.w;
     }

@@ -646,8 +646,6 @@ def localmd_decomposition(
         # handed to it as nvt "virtual tiles" per tile, [n * nvt][64][x], the same memory (see below, after the assembly).
         rpad = int(lib.pmd_tile_rpad(int(max_components)))
         nvt = rpad // 64
-        if nvt > 1 and n_win > 1:
-            raise ValueError("window_chunks < frame_range (residual windows) is supported up to max_components = 54 (got {})".format(max_components))
         pix_dev = _i32(ctx, pix_c)
         pool_q_dev, pool_idx_dev, pool_w_dev = _i32(ctx, pool_q), _i32(ctx, pool_idx), _f32(ctx, pool_w)
 
@@ -724,10 +722,10 @@ def localmd_decomposition(
             # the Gaussian matrix of (tile, window) is logical array tile * n_win + window
             ld_w = lib.pmd_time_ld(win_len)
             xw = torch.zeros((movie.rows_alloc, ld_w), dtype=torch.float32, device=ctx.device)
-            vw = torch.empty((n_loc, 64, ld_w), dtype=torch.float32, device=ctx.device)
-            st_w = torch.zeros((n_loc, 64, 2), dtype=torch.float32, device=ctx.device)
-            gd_w = torch.zeros((n_loc, 64), dtype=torch.int32, device=ctx.device)
-            kp_w = torch.zeros((n_loc, 64), dtype=torch.int32, device=ctx.device)
+            vw = torch.empty((n_loc, rpad, ld_w), dtype=torch.float32, device=ctx.device)
+            st_w = torch.zeros((n_loc, rpad, 2), dtype=torch.float32, device=ctx.device)
+            gd_w = torch.zeros((n_loc, rpad), dtype=torch.int32, device=ctx.device)
+            kp_w = torch.zeros((n_loc, rpad), dtype=torch.int32, device=ctx.device)
             for widx, w0 in enumerate(win_starts):
                 xw[:Dl, :win_len] = xf[:Dl, w0:w0 + win_len]
                 if widx == 0:
@@ -740,7 +738,7 @@ def localmd_decomposition(
                                            ptr(keep_dev[t_lo:]), ptr(ranks_dev[t_lo:]), ptr(lam_dev[t_lo:])), ws,
                                      (n_loc, b1, b2, P_pool, r, a_f, win_len, ld_w, Dl, dpad), temporal_denoiser,
                                      spatial_denoiser)
-                    ctx.call("pmd_tiles_truncate", ptr(ut_dev[t_lo:]), dpad, ptr(ranks_dev[t_lo:]), n_loc)
+                    ctx.call("pmd_tiles_truncate", ptr(ut_dev[t_lo:]), dpad, ptr(ranks_dev[t_lo:]), n_loc, rpad)
                 else:
                     ws = ctx.workspace(lib.pmd_tiles_residual_workspace_bytes(n_loc, b1, b2, r, a_f, win_len, Dl))
                     ctx.call("pmd_tiles_residual", ptr(xw), ld_w, Dl, win_len, ptr(pix_loc_dev), n_loc, b1, b2, r, a_f,
@@ -748,7 +746,9 @@ def localmd_decomposition(
                              ptr(ut_dev[t_lo:]), ptr(ranks_dev[t_lo:]), ptr(st_w), ptr(gd_w), ptr(kp_w), ptr(ws), ws.numel())
             del xw, vw
             # temporal traces over all fitted frames: U_b^T X (get_temporal_projector, decomposition.py:518-523)
-            ctx.call("pmd_tiles_project", ptr(xf), ld_f, crop, ptr(pix_loc_dev), n_loc, d, ptr(ut_dev[t_lo:]), dpad,
+            # (blocks of 64 component rows: a tile with rpad = 64 nvt rows is nvt such blocks with the same pixels)
+            pix_blocks = pix_loc_dev if nvt == 1 else pix_loc_dev.repeat_interleave(nvt, dim=0)
+            ctx.call("pmd_tiles_project", ptr(xf), ld_f, crop, ptr(pix_blocks), n_loc * nvt, d, ptr(ut_dev[t_lo:]), dpad,
                      ptr(v_dev[t_lo:]), ldv, 2)
         for tns in (ut_dev, stats_dev, good_dev, keep_dev, ranks_dev, lam_dev):
             dist.gather_runs(tns, runs)

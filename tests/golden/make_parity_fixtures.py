@@ -30,7 +30,7 @@ CASES = {
     # name: movie arguments, decomposition arguments (shared verbatim with the test through the fixture's "case" entry)
     "rle": dict(T=10000, d1=128, d2=128, block=20, movie_seed=5, ladder=24, ladder_top=120.0, ladder_ratio=0.9,
                 max_components=50, seed=321, np_seed=11, sim_iters=20),
-    "headline": dict(T=10000, d1=256, d2=256, block=20, movie_seed=6, ladder=28, ladder_top=80.0, ladder_ratio=0.91, ladder_smooth=8.0,
+    "headline": dict(T=10000, d1=352, d2=352, block=20, movie_seed=6, ladder=28, ladder_top=80.0, ladder_ratio=0.91, ladder_smooth=8.0,
                      max_components=50, seed=654, np_seed=12, sim_iters=20),
 }
 

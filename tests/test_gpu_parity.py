@@ -442,6 +442,19 @@ def test_full_pipeline_multi_window_residual(gpu_ctx):
     assert np.any(ref.diag["tile_ranks"] > first)
 
 
+def test_full_pipeline_multi_window_residual_max_components_70(gpu_ctx):
+    """Residual windows on the generic-width path (max_components + 10 > 64: 128 component rows per tile): the first window
+    through the wide single_block_md, the second through the wide single_residual_block_md (decomposition.py:333-387), then
+    the projection of the running basis over all fitted frames in blocks of 64 component rows."""
+    mov = _movie(1700, 40, 44, seed=31)
+    pmd, diag, ref = _compare_full(gpu_ctx, mov, (20, 20), 1600, max_components=70, background_rank=2, sim_iters=10,
+                                   window_chunks=800)
+    assert len(diag["frames"]) == 1600 and diag["max_components"] == 70
+    _check_full(pmd, diag, ref, mov, vt_tol=3e-3)
+    first = np.array([d[0]["kept"].sum() for d in ref.diag["tile_diag"]])
+    assert np.any(ref.diag["tile_ranks"] > first)
+
+
 def test_full_pipeline_max_components_beyond_time_bins(gpu_ctx):
     """max_components larger than frames / temporal_avg_factor: the reference's rSVD keeps its (max_components + 10)-column
     sketch and returns the components that exist (decomposition.py:59-73, `u_final[:, :rank]`); no error."""
