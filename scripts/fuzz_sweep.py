@@ -1,14 +1,14 @@
 """Fresh seeded draws through the assertions of tests/test_gpu_fuzz.py (beyond the ten cases of the graded suite).
-    python scripts/fuzz_sweep.py FAMILY SEED N [case ...]    FAMILY = base (the draws of round 1) | wide (many tiles, R > frames) | options (the rest of the option space) | edge (extremes; both sides must refuse the same inputs) | medium (larger movies, minutes of oracle time) | tall (config-2-like: R several times the frames)"""
+    python scripts/fuzz_sweep.py FAMILY SEED N [case ...]    FAMILY = base (the draws of round 1) | wide (many tiles, R > frames) | options (the rest of the option space) | edge (extremes; both sides must refuse the same inputs) | medium (larger movies, minutes of oracle time) | tall (config-2-like: R several times the frames) | widecomp (max_components 55-110, background_rank up to 64: the generic-width path)"""
 import os, sys, time, traceback
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from tests.test_gpu_fuzz import draw_cases, draw_wide_cases, draw_option_cases, draw_edge_cases, draw_medium_cases, draw_tall_cases, run_case, check_case
+from tests.test_gpu_fuzz import draw_cases, draw_wide_cases, draw_option_cases, draw_edge_cases, draw_medium_cases, draw_tall_cases, draw_widecomp_cases, run_case, check_case
 from localmd_amd._lib import Context
 
 if __name__ == "__main__":
     family, seed, n = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
     only = [int(a) for a in sys.argv[4:]]
-    cases = {"base": draw_cases, "wide": draw_wide_cases, "options": draw_option_cases, "edge": draw_edge_cases, "medium": draw_medium_cases, "tall": draw_tall_cases}[family](n, seed)
+    cases = {"base": draw_cases, "wide": draw_wide_cases, "options": draw_option_cases, "edge": draw_edge_cases, "medium": draw_medium_cases, "tall": draw_tall_cases, "widecomp": draw_widecomp_cases}[family](n, seed)
     if only:
         cases = [c for c in cases if c[0] in only]
     ctx = Context(0)

@@ -81,7 +81,10 @@ def test_config2_full_parity(gpu_ctx):
     # against the arbiter itself the HIP path holds tighter figures than against the fp32 oracle
     mh = res["measures"]["HIP vs arbiter fp64"]
     sig = mh["signal"]
-    assert mh["s_rel"][sig].max() < 1e-4 and mh["vt_row_err"][sig].max() < 1e-3 and mh["u_data_err_stable"] < 2e-5
+    # (round 3, chunked fp32 accumulation + fp64 eigenvector refinement: s 2.5e-6, Vt 4.0e-5, U_data 2.8e-6 - the NORTH STAR's
+    # Vt < 1e-4, against the exact result of the reference's algorithm, at a BASELINE configuration with R > frames)
+    assert mh["s_rel"][sig].max() < 2e-5 and mh["vt_row_err"][sig].max() < 1e-4 and mh["u_data_err_stable"] < 1e-5, \
+        (mh["s_rel"][sig].max(), mh["vt_row_err"][sig].max(), mh["u_data_err_stable"])
 
 
 def _run_fixture_case(gpu_ctx, name):

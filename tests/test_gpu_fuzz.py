@@ -99,6 +99,40 @@ def draw_option_cases(n_cases, seed):
     return out
 
 
+def draw_widecomp_cases(n_cases, seed):
+    """Draws on the generic-width tile path (round 3): max_components 55 ... 110 (128-row tiles), background_rank up to 64
+    (generic-width background rSVD above 54), with the other options of draw_option_cases - residual windows, rank_prune,
+    pixel weights, both pixel orders, several consecutive failures (which is what lets a tile keep more than 64 components)."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for case in range(n_cases):
+        b1, b2 = (int(2 * rng.integers(7, 17)) for _ in range(2))
+        d1 = int(rng.integers(b1, int(2.2 * b1) + 6))
+        d2 = int(rng.integers(b2, int(2.2 * b2) + 6))
+        taf = int(rng.choice([2, 5, 10]))
+        saf = int(rng.choice([1, 2]))
+        T = int(rng.integers(700, 1300))
+        frames = T if rng.random() < 0.6 else int(rng.integers(600, T))
+        pooled = (-(-b1 // saf)) * (-(-b2 // saf))
+        r_max = min(110, frames // taf - 1, max(56, pooled))
+        r = int(rng.integers(55, max(56, r_max) + 1))
+        kw = dict(max_components=r, background_rank=int(rng.choice([0, 3, 15, 40, 58, 64])),
+                  temporal_avg_factor=taf, spatial_avg_factor=saf, order=str(rng.choice(["F", "C"])),
+                  max_consecutive_failures=int(rng.choice([1, 1, 3, 100])))
+        if rng.random() < 0.25:
+            kw["rank_prune"] = True
+            kw["rank_prune_factor"] = float(rng.choice([0.3, 0.6]))
+        if rng.random() < 0.25:
+            kw["pixel_weighting"] = (0.5 + np.random.default_rng(seed * 1000 + case).random((d1, d2))).astype(np.float32)
+        if rng.random() < 0.3:
+            wc = int(frames // 2 // taf * taf)
+            if wc // taf > r:
+                kw["window_chunks"] = wc
+        extra = {"noise": float(rng.choice([0.5, 1.0])), "dtype": "float32"}
+        out.append((case, T, d1, d2, b1, b2, frames, kw, extra))
+    return out
+
+
 def draw_edge_cases(n_cases, seed):
     """Draws at the edges of the argument space: fewer than 256 frames (one Welch segment), FOV equal to or barely larger
     than a block, frame counts that are no multiple of the temporal factor, one or two components, background ranks

@@ -579,6 +579,16 @@ def test_full_pipeline_denoiser_hooks(gpu_ctx, which):
     assert plain.u.shape != pmd.u.shape or not np.allclose(plain.u.data, pmd.u.data, rtol=1e-4, atol=1e-6)
 
 
+def test_full_pipeline_denoiser_hooks_generic_width(gpu_ctx):
+    """Both hooks on the generic-width tile path (max_components = 60: 128 component rows; the three resumable stages of
+    tiles_decompose_wide with the hook arrays at their rp-row offsets)."""
+    mov = _movie(900, 40, 50, seed=33)
+    kw = dict(max_components=60, background_rank=2, sim_iters=10, temporal_denoiser=_smooth_time, spatial_denoiser=_smooth_space)
+    pmd, diag, ref = _compare_full(gpu_ctx, mov, (20, 20), 900, **kw)
+    assert diag["max_components"] == 60
+    _check_full(pmd, diag, ref, mov, vt_tol=3e-3)
+
+
 def test_denoiser_hooks_batched_and_first_window_only(gpu_ctx):
     """A callable marked ``batched`` sees all tiles at once and gives the same result as the per-tile calls; with
     several temporal windows the hooks act in the first window only (decomposition.py:476-488)."""
