@@ -199,6 +199,17 @@ int pmd_orthogonalize_factored(pmd_ctx* ctx, const float* M, int Rc, int m, long
 int pmd_orthogonalize_chol(pmd_ctx* ctx, const float* M, int Rc, int m, long ldm, const float* GM, long ldgm,
                            float* Et_out, long lde, int* ok_host, void* ws, size_t ws_bytes);
 size_t pmd_orthogonalize_chol_workspace_bytes(int Rc, int m);
+/* The frames x frames part of pmd_projected_svd_factored split by frame columns (multi-GPU: every rank owns T / N columns of
+ * W1 = M^T Z; decomposition.py:1089-1099 is the reference step).  pmd_psvd_vp_gram: Vp (rp x nc) = Et (rp x m) W1[:, c0:c0+nc)
+ * (W1 points at the first owned column, leading dimension ldw; et_lower: Et is lower triangular) and C = Vp Vp^T (rp x rp,
+ * ldc >= round_up(rp, 4), row-major upper triangle) - the caller sums C over the ranks (all-reduce).  pmd_psvd_finish:
+ * eigendecomposition of the summed C (every rank the same), s_out (rp), W_out (rp x rp), Vt_out (rp x nc) = this rank's columns
+ * of W^T Vp / s.  One rank with nc = T reproduces pmd_projected_svd_factored. */
+int pmd_psvd_vp_gram(pmd_ctx* ctx, const float* Et, int rp, int m, long lde, const float* W1, int nc, long ldw, int et_lower, float* Vp,
+                     long ldv, float* C, long ldc);
+size_t pmd_psvd_finish_workspace_bytes(int rp);
+int pmd_psvd_finish(pmd_ctx* ctx, float* C, long ldc, int rp, const float* Vp, int nc, long ldv, float* W_out, long ldw, float* s_out,
+                    float* Vt_out, long ldvt, void* ws, size_t ws_bytes);
 size_t pmd_projected_svd_factored_workspace_bytes(int Rc, int m, int rp, int T);
 int pmd_projected_svd_factored(pmd_ctx* ctx, const float* M, int Rc, int m, long ldm, const float* Et, int rp, long lde,
                                const float* Z, int T, long ldz, float* R_out, long ldr, float* s_out, float* Vt_out,

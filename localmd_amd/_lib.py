@@ -84,6 +84,9 @@ SIGNATURES = {
     "pmd_comm_all_reduce_f32": (c_i, [c_p, c_p, c_sz]),
     "pmd_comm_all_gather": (c_i, [c_p, c_p, c_p, c_sz]),
     "pmd_transpose": (c_i, [c_p, c_p, c_l, c_i, c_i, c_p, c_l]),
+    "pmd_psvd_vp_gram": (c_i, [c_p, c_p, c_i, c_i, c_l, c_p, c_i, c_l, c_i, c_p, c_l, c_p, c_l]),
+    "pmd_psvd_finish_workspace_bytes": (c_sz, [c_i]),
+    "pmd_psvd_finish": (c_i, [c_p, c_p, c_l, c_i, c_p, c_i, c_l, c_p, c_l, c_p, c_p, c_l, c_p, c_sz]),
     "pmd_csr_count": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_p]),
     "pmd_csr_fill": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_i,
                            c_p, c_p, c_p, c_p, c_i]),

@@ -392,6 +392,19 @@ int pmd_transpose(pmd_ctx* ctx, const float* src, long ld_src, int rows, int col
   CTX_CHECK(ctx);
   return pmd_transpose_impl(ctx, src, ld_src, rows, cols, dst, ld_dst);
 }
+int pmd_psvd_vp_gram(pmd_ctx* ctx, const float* Et, int rp, int m, long lde, const float* W1, int nc, long ldw, int et_lower, float* Vp,
+                     long ldv, float* C, long ldc) {
+  CTX_CHECK(ctx);
+  if (rp < 1 || m < rp || nc < 0 || ldc < rp) return pmd_fail(ctx, PMD_ERR_ARG, "pmd_psvd_vp_gram", "bad shape");
+  return pmd_psvd_vp_gram_impl(ctx, Et, rp, m, lde, W1, nc, ldw, et_lower, Vp, ldv, C, ldc);
+}
+size_t pmd_psvd_finish_workspace_bytes(int rp) { return pmd_psvd_finish_workspace_bytes_impl(rp); }
+int pmd_psvd_finish(pmd_ctx* ctx, float* C, long ldc, int rp, const float* Vp, int nc, long ldv, float* W_out, long ldw, float* s_out,
+                    float* Vt_out, long ldvt, void* ws, size_t ws_bytes) {
+  CTX_CHECK(ctx);
+  if (rp < 1 || nc < 0 || ldc < rp) return pmd_fail(ctx, PMD_ERR_ARG, "pmd_psvd_finish", "bad shape");
+  return pmd_psvd_finish_impl(ctx, C, ldc, rp, Vp, nc, ldv, W_out, ldw, s_out, Vt_out, ldvt, ws, ws_bytes);
+}
 size_t pmd_projected_svd_factored_workspace_bytes(int Rc, int m, int rp, int T) {
   return pmd_projected_svd_factored_workspace_bytes_impl(Rc, m, rp, T);
 }

@@ -583,6 +583,90 @@ int pmd_projected_svd_impl(pmd_ctx* ctx, const float* P, int rows_p, long ldp, c
   return PMD_OK;
 }
 
+// ---------------------------------------------------------------- A17 split by frame columns ------------------
+// Multi-GPU form of the factored projected SVD (the frames x frames products of the last stage sharded by frame columns):
+//   pmd_psvd_vp_gram : Vp_r = Et W1[:, c0:c1) for this rank's frame columns, C_r = Vp_r Vp_r^T (row-major upper triangle)
+//   [the caller sums C_r over the ranks]
+//   pmd_psvd_finish  : eigendecomposition of the summed C (replicated), s, W, and this rank's columns of Vt = W^T Vp / s
+// One rank with all columns reproduces pmd_projected_svd_factored (same kernels, same order of operations).
+static int psvd_gram_rows(pmd_ctx* ctx, const float* V, int n1, int n2, long ldv, float* C, long ldc) {
+  pmd_prof_scope prof__(ctx, "rocblas_ssyrk");
+  const float one = 1.f, zero = 0.f;
+  const int kc = pmd_gemm_k_chunk(n2);
+  if (n2 <= 0) { PMD_HIP(ctx, hipMemsetAsync(C, 0, (size_t)n1 * ldc * sizeof(float), ctx->stream)); return PMD_OK; }
+  for (int k0 = 0; k0 < n2; k0 += kc) {
+    const int kk = std::min(kc, n2 - k0);
+    PMD_BLAS(ctx, rocblas_ssyrk(ctx->blas, rocblas_fill_lower, rocblas_operation_transpose, n1, kk, &one, V + k0, (rocblas_int)ldv,
+                                k0 == 0 ? &zero : &one, C, (rocblas_int)ldc));
+  }
+  return PMD_OK;
+}
+
+int pmd_psvd_vp_gram_impl(pmd_ctx* ctx, const float* Et, int rp, int m, long lde, const float* W1, int nc, long ldw, int et_lower,
+                          float* Vp, long ldv, float* C, long ldc) {
+  if (nc > 0) {
+    const bool tri = et_lower && rp == m;
+    const float one = 1.f;
+    if (tri) {
+      pmd_prof_scope prof__(ctx, "rocblas_strmm");
+      PMD_BLAS(ctx, rocblas_strmm(ctx->blas, rocblas_side_right, rocblas_fill_upper, rocblas_operation_none, rocblas_diagonal_non_unit, nc, m,
+                                  &one, Et, (rocblas_int)lde, W1, (rocblas_int)ldw, Vp, (rocblas_int)ldv));
+    } else {
+      RUN(pmd_gemm_rm(ctx, 0, 0, rp, nc, m, 1.f, Et, lde, W1, ldw, 0.f, Vp, ldv));
+    }
+  }
+  return psvd_gram_rows(ctx, Vp, rp, nc, ldv, C, ldc);
+}
+
+size_t pmd_psvd_finish_workspace_bytes_impl(int rp) {
+  return (size_t)rp * rp * sizeof(float) + (size_t)rp * (sizeof(float) * 5 + sizeof(int)) + 16384;
+}
+
+// C: summed Gram matrix (rp x rp, ld ldc >= round_up(rp, 4); overwritten), Vp: this rank's columns (rp x nc).
+// Outputs: W_out (rp x rp, row c' = component c' of the left vectors, i.e. W[c'][c]), s_out (rp), Vt_out (rp x nc).
+int pmd_psvd_finish_impl(pmd_ctx* ctx, float* C, long ldc, int rp, const float* Vp, int nc, long ldv, float* W_out, long ldw, float* s_out,
+                         float* Vt_out, long ldvt, void* ws, size_t ws_bytes) {
+  pmd_arena ar(ws, ws_bytes);
+  float* Wt = ar.take_n<float>((size_t)rp * rp);
+  float* w = ar.take_n<float>(rp);
+  float* work = ar.take_n<float>(rp);
+  float* sgn = ar.take_n<float>(rp);
+  float* inv = ar.take_n<float>(rp);
+  int* perm = ar.take_n<int>(rp);
+  int* info = ar.take_n<int>(4);
+  if (ar.overflow) return pmd_fail(ctx, PMD_ERR_WORKSPACE, "pmd_psvd_finish", "workspace too small");
+  RUN(pmd_syevd(ctx, rp, C, ldc, w, work, info));
+  std::vector<float> hw(rp);
+  int hinfo = 0;
+  PMD_HIP(ctx, hipMemcpyAsync(hw.data(), w, (size_t)rp * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+  PMD_HIP(ctx, hipMemcpyAsync(&hinfo, info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  PMD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (hinfo != 0) return pmd_fail(ctx, PMD_ERR_BLAS, "rocsolver_ssyevd", "did not converge");
+  std::vector<int> idx(rp);
+  for (int i = 0; i < rp; ++i) idx[i] = i;
+  std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return std::fabs(hw[a]) > std::fabs(hw[b]); });
+  std::vector<float> hs(rp), hsgn(rp), hinv(rp);
+  for (int i = 0; i < rp; ++i) {
+    const float lam = hw[idx[i]];
+    hs[i] = std::sqrt(std::fabs(lam));
+    hsgn[i] = (lam < 0.f) ? -1.f : 1.f;
+    hinv[i] = (hs[i] == 0.f) ? 1.f : 1.f / hs[i];
+  }
+  PMD_HIP(ctx, hipMemcpyAsync(perm, idx.data(), (size_t)rp * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+  PMD_HIP(ctx, hipMemcpyAsync(sgn, hsgn.data(), (size_t)rp * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  PMD_HIP(ctx, hipMemcpyAsync(inv, hinv.data(), (size_t)rp * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  PMD_HIP(ctx, hipMemcpyAsync(s_out, hs.data(), (size_t)rp * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  RUN(launch_gather_rows(ctx, C, ldc, perm, sgn, rp, rp, Wt, rp));      // Wt[c][:] = sign_c * eigenvector perm[c]
+  if (nc > 0) {
+    RUN(pmd_gemm_rm(ctx, 0, 0, rp, nc, rp, 1.f, Wt, rp, Vp, ldv, 0.f, Vt_out, ldvt));
+    hipLaunchKernelGGL(scale_rows2_kernel, dim3(8, rp), dim3(256), 0, ctx->stream, Vt_out, ldvt, nc, inv);
+    PMD_LAUNCH_CHECK(ctx, "scale_rows2_kernel");
+  }
+  RUN(launch_transpose(ctx, Wt, rp, rp, rp, W_out, ldw));
+  PMD_HIP(ctx, hipStreamSynchronize(ctx->stream));   // the host vectors above are temporaries
+  return PMD_OK;
+}
+
 // ---------------------------------------------------------------- background projection ----
 // out[k][t] = sum_c basis[c][k] * xs[c][t]  (pmd_loader.py:386, and the K background rows of
 // U^T X in :411).  xs must have round_up(D, 1024) rows allocated (rows >= D zero).

@@ -164,6 +164,11 @@ int pmd_projected_svd_factored_impl(pmd_ctx* ctx, const float* M, int Rc, int m,
                                     long lde, const float* Z, int T, long ldz, float* R_out, long ldr, float* s_out,
                                     float* Vt_out, long ldvt, float* Vp_out, long ldvp, float* X1_out,
                                     const float* W1_in, int et_lower, void* ws, size_t ws_bytes);
+int pmd_psvd_vp_gram_impl(pmd_ctx* ctx, const float* Et, int rp, int m, long lde, const float* W1, int nc, long ldw, int et_lower,
+                          float* Vp, long ldv, float* C, long ldc);
+size_t pmd_psvd_finish_workspace_bytes_impl(int rp);
+int pmd_psvd_finish_impl(pmd_ctx* ctx, float* C, long ldc, int rp, const float* Vp, int nc, long ldv, float* W_out, long ldw, float* s_out,
+                         float* Vt_out, long ldvt, void* ws, size_t ws_bytes);
 size_t pmd_gram_mtgm_workspace_bytes_impl(int rows, int m);
 int pmd_gram_mtgm_impl(pmd_ctx* ctx, const float* M, int rows, int m, long ldm, const float* GM, long ldgm, float* C,
                        long ldc, void* ws, size_t ws_bytes);

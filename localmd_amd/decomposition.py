@@ -1153,10 +1153,42 @@ def localmd_decomposition(
             X1 = torch.empty((m_used, rp), dtype=torch.float32, device=ctx.device)
             # W1 = M^T Z was formed next to the Cholesky step (summed over the ranks when the rows are sharded);
             # None on the eigenvector route (formed inside the call)
-            ws = ctx.workspace(lib.pmd_projected_svd_factored_workspace_bytes(Rc, m_used, rp, T))
-            ctx.call("pmd_projected_svd_factored", ptr(right), Rc, m_used, m_cols, ptr(Et_dev), rp, m_cols, ptr(Z), T, T,
-                     None, nk, ptr(s_out), ptr(Vt_out), T, ptr(Vp), T, ptr(X1), ptr(W1), 1 if chol_ok else 0, ptr(ws),
-                     ws.numel())
+            if shard:
+                # The frames x frames products of the last stage by FRAME COLUMNS (round 3): rank r forms its T / N columns
+                # of Vp = Et W1 and their Gram matrix; the partial Gram matrices are all-reduced (one more m x m exchange);
+                # the eigensolver runs replicated; every rank then forms its columns of Vt, which travel to rank 0.
+                cparts = tile_partition(T, dist.world)
+                c0, c1 = cparts[dist.rank]
+                nc = c1 - c0
+                ldc = _round_up(rp, 4)
+                Vp_r = torch.empty((rp, max(nc, 1)), dtype=torch.float32, device=ctx.device)
+                Cg = torch.zeros((rp, ldc), dtype=torch.float32, device=ctx.device)
+                ctx.call("pmd_psvd_vp_gram", ptr(Et_dev), rp, m_used, m_cols, ptr(W1.view(-1)[c0:]), nc, T, 1 if chol_ok else 0,
+                         ptr(Vp_r), max(nc, 1), ptr(Cg), ldc)
+                dist.all_reduce(Cg)
+                Wmat = torch.empty((rp, rp), dtype=torch.float32, device=ctx.device)
+                Vt_r = torch.empty((rp, max(nc, 1)), dtype=torch.float32, device=ctx.device)
+                ws = ctx.workspace(lib.pmd_psvd_finish_workspace_bytes(rp))
+                ctx.call("pmd_psvd_finish", ptr(Cg), ldc, rp, ptr(Vp_r), nc, max(nc, 1), ptr(Wmat), rp, ptr(s_out), ptr(Vt_r),
+                         max(nc, 1), ptr(ws), ws.numel())
+                ctx.call("pmd_gemm", 1, 0, m_used, rp, rp, 1.0, ptr(Et_dev), m_cols, ptr(Wmat), rp, 0.0, ptr(X1), rp)
+                ctx.sync()
+                blocks = dist.gather_blocks_to_root(Vt_r[:, :nc].contiguous(), [(rp, b_ - a_) for a_, b_ in cparts])
+                if blocks is not None:
+                    for (a_, b_), blk in zip(cparts, blocks):
+                        if b_ > a_:
+                            Vt_out[:rp, a_:b_] = blk
+                if Vp is not None:      # diagnostics only: every rank gets the whole V = P^T Z (a sum of disjoint column blocks)
+                    Vp.zero_()
+                    if nc > 0:
+                        Vp[:, c0:c1] = Vp_r[:, :nc]
+                    dist.all_reduce(Vp)
+                del Vp_r, Cg, Vt_r, Wmat
+            else:
+                ws = ctx.workspace(lib.pmd_projected_svd_factored_workspace_bytes(Rc, m_used, rp, T))
+                ctx.call("pmd_projected_svd_factored", ptr(right), Rc, m_used, m_cols, ptr(Et_dev), rp, m_cols, ptr(Z), T, T,
+                         None, nk, ptr(s_out), ptr(Vt_out), T, ptr(Vp), T, ptr(X1), ptr(W1), 1 if chol_ok else 0, ptr(ws),
+                         ws.numel())
             p_null = None
             if null_tail:
                 # the kept null direction: P column = right Et[m-1, :]^T, V row = Et[m-1, :] (right^T Z), its own

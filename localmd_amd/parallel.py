@@ -154,6 +154,37 @@ class Dist:
                     if self.rank == 0 and on_block is not None:
                         on_block(lo, hi)
 
+    def gather_blocks_to_root(self, block, shapes):
+        """Every rank holds one contiguous 2-D block (``shapes[r]`` = its shape on rank r; a dimension may be 0); rank 0
+        returns the list of all blocks (its own included), the other ranks return None.  RCCL: point-to-point sends into
+        rank 0, all receives posted at once; other backends: one broadcast per owner."""
+        if not self.enabled:
+            return [block]
+        import torch.distributed as dist
+
+        def grank(r):
+            return dist.get_global_rank(self.group, r) if self.group is not None else r
+
+        nonempty = [r for r, sh in enumerate(shapes) if sh[0] * sh[1] > 0]
+        out = None
+        if self.rank == 0:
+            out = [block if r == 0 else block.new_empty(tuple(sh)) for r, sh in enumerate(shapes)]
+        if dist.get_backend(self.group) == "nccl":
+            if self.rank == 0:
+                ops = [dist.P2POp(dist.irecv, out[r], grank(r), self.group) for r in nonempty if r != 0]
+                for req in (dist.batch_isend_irecv(ops) if ops else []):
+                    req.wait()
+            elif self.rank in nonempty:
+                for req in dist.batch_isend_irecv([dist.P2POp(dist.isend, block.contiguous(), grank(0), self.group)]):
+                    req.wait()
+        else:
+            for r in nonempty:
+                if r == 0:
+                    continue
+                buf = out[r] if self.rank == 0 else (block.contiguous() if self.rank == r else block.new_empty(tuple(shapes[r])))
+                dist.broadcast(buf, src=grank(r), group=self.group)
+        return out
+
     def barrier(self):
         if self.enabled:
             import torch.distributed as dist

@@ -1,9 +1,11 @@
 """
 The distributed decomposition (localmd_decomposition(distributed=True), one process per rank) against the single-rank
 result, run as fresh child processes: 2 ranks over gloo sharing the one GPU of the test box (the RCCL branch of the
-collectives needs one GPU per rank and is exercised by `bench.py --gpus N` on a multi-GPU node).  Six configurations
+collectives needs one GPU per rank and is exercised by `bench.py --gpus N` on a multi-GPU node).  Seven configurations
 (scripts/dist_check.py): R <= frames, R > frames (row-sharded Cholesky route with the halo exchange of the right
-matrix), a frame subset with pixel weights in C order, several temporal windows, denoiser hooks, rank_prune.
+matrix and, since round 3, the frames x frames products of the last stage sharded by frame columns), a frame subset with pixel
+weights in C order, several temporal windows, denoiser hooks, rank_prune, and the generic-width tile path (max_components 80, every
+component kept: virtual tiles of 64 component rows in the sharded global stage).
 Tile ranks, CSR structure and the statistics images must equal the single-rank ones; floating-point results agree to
 fp32 summation order.
 """
@@ -41,4 +43,4 @@ def test_distributed_matches_single_rank(gpu_ctx, world):
         pytest.fail("distributed run did not finish within 300 s:\n" + stdout[-4000:])
     print(stdout[-6000:])
     assert proc.returncode == 0, stdout[-3000:]
-    assert stdout.count("ok=True") == 6 * world and "ok=False" not in stdout
+    assert stdout.count("ok=True") == 7 * world and "ok=False" not in stdout

@@ -361,6 +361,15 @@ OPTION_CASES = [(22, 3), (22, 10), (22, 13), (22, 45), (21, 7), (21, 16), (23, 1
 _OPTION = {(sd, c[0]): c for sd in (21, 22, 23) for c in draw_option_cases(48, sd)}
 
 
+# the generic-width family (round 3; 28 draws swept over two seeds).  Seed 1: draw 0 = max_components 108 with residual windows
+# and background_rank 64; draw 1 = every component of 30 x 28-pixel tiles kept (max_consecutive_failures 100, 88 components,
+# two blocks of 64 rows per tile in the global stage), R > frames in the unresolvable regime - the draw that showed the
+# double-precision eigenvalue paths amplifying null directions beyond anything the reference's fp32 arithmetic does;
+# draw 4 = rank_prune with 84 components and 58 background columns, C order; draw 10 = pixel weights + windows at 109.
+WIDECOMP_CASES = [(1, 0), (1, 1), (1, 4), (1, 10)]
+_WIDECOMP = {(1, c[0]): c for c in draw_widecomp_cases(16, 1)}
+
+
 def check_case(fig):
     """The assertions of one draw (shared with scripts/fuzz_sweep.py)."""
     pmd, ref = fig["pmd"], fig["ref"]
@@ -425,5 +434,13 @@ def test_fuzz_wide_case(gpu_ctx, case):
 def test_fuzz_option_case(gpu_ctx, seed, case):
     lines = []
     fig = run_case(gpu_ctx, *_OPTION[(seed, case)], out=lines.append)
+    print("\n".join(lines))
+    check_case(fig)
+
+
+@pytest.mark.parametrize("seed,case", WIDECOMP_CASES)
+def test_fuzz_widecomp_case(gpu_ctx, seed, case):
+    lines = []
+    fig = run_case(gpu_ctx, *_WIDECOMP[(seed, case)], out=lines.append)
     print("\n".join(lines))
     check_case(fig)

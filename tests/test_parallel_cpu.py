@@ -167,3 +167,44 @@ def test_exchange_rows_world3_gloo(tmp_path):
             have[lo:hi] = True
         np.testing.assert_array_equal(got[have], full[have])
         assert np.all(got[~have] == -1.0)
+
+
+def _worker_blocks(rank, world, port, out_dir):
+    """Column blocks of Vt collected on rank 0 (round 3: the frames x frames products sharded by frame columns), and the
+    partial Gram matrices of the column blocks summed to the Gram matrix of the whole."""
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        d = Dist(True)
+        T, rp = 11, 4          # 11 frame columns over 3 ranks: 4, 4, 3 (and a rank with none when T < world)
+        for T_ in (T, 2):
+            cparts = tile_partition(T_, world)
+            c0, c1 = cparts[rank]
+            full = torch.arange(rp * T_, dtype=torch.float32).reshape(rp, T_) * 0.5 + 1.0
+            mine = full[:, c0:c1].contiguous()
+            blocks = d.gather_blocks_to_root(mine, [(rp, b - a) for a, b in cparts])
+            gram = mine @ mine.T
+            d.all_reduce(gram)
+            if rank == 0:
+                got = torch.cat([b for b in blocks if b.shape[1] > 0], dim=1)
+                assert torch.equal(got, full), (got, full)
+            else:
+                assert blocks is None
+            assert torch.allclose(gram, full @ full.T)
+        d.barrier()
+        open(os.path.join(out_dir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_gather_column_blocks_and_partial_gram_gloo(tmp_path, world):
+    import torch.multiprocessing as mp
+
+    port = _free_port()
+    mp.spawn(_worker_blocks, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(world))
