@@ -178,7 +178,8 @@ size_t pmd_projected_svd_workspace_bytes(int rows_p, int n1, int n2);
 int pmd_projected_svd(pmd_ctx* ctx, const float* P, int rows_p, long ldp, const float* V, int n1, int n2, long ldv,
                       float* R_out, long ldr, float* s_out, float* Vt_out, long ldvt, void* ws, size_t ws_bytes);
 /* Block-sparse form of the same Gram matrix, used when R > frames (right_mat = v, decomposition.py:976-981):
- * Gblk[pair][64][64], Gbg[tile][64][64] (tile x background), Gstrip[K][ldgs] (background rows of G).
+ * Gblk[pair][64][64], Gbg[kb][tile][64][64] (tile x block kb of 64 background columns; ceil(K / 64) blocks), Gstrip[K][ldgs]
+ * (background rows of G).
  * pmd_gram_apply: GM = G M without densifying G.  nbr_ptr[n_tiles+1], nbr[e] = (first M row of the
  * block, rows in it, block index, flags: bit0 transposed, bit1 background block). */
 int pmd_gram_blocks(pmd_ctx* ctx, const float* Uw, int dpad, int b1, int b2, const int* tile_pix, const int* pairs,

@@ -672,12 +672,12 @@ int pmd_psvd_finish_impl(pmd_ctx* ctx, float* C, long ldc, int rp, const float* 
 // U^T X in :411).  xs must have round_up(D, 1024) rows allocated (rows >= D zero).
 #define BGP_BLK 1024
 
-__global__ void block_basis_kernel(const float* __restrict__ basis, long D, int K, float* __restrict__ At) {
-  // At[blk][k][q] = basis[blk*BGP_BLK + q][k]
+__global__ void block_basis_kernel(const float* __restrict__ basis, long D, int K, float* __restrict__ At, int kstride) {
+  // At[blk][k][q] = basis[blk*BGP_BLK + q][k]   (K <= 64 columns of a basis with kstride columns per pixel)
   const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long blk = c / BGP_BLK;
   const int q = (int)(c - blk * BGP_BLK);
-  for (int k = 0; k < PMD_RPAD; ++k) At[blk * PMD_RPAD * BGP_BLK + (long)k * BGP_BLK + q] = (c < D && k < K) ? basis[c * K + k] : 0.f;
+  for (int k = 0; k < PMD_RPAD; ++k) At[blk * PMD_RPAD * BGP_BLK + (long)k * BGP_BLK + q] = (c < D && k < K) ? basis[c * kstride + k] : 0.f;
 }
 
 size_t pmd_bg_project_workspace_bytes_impl(long D, int T) {
@@ -687,19 +687,23 @@ size_t pmd_bg_project_workspace_bytes_impl(long D, int T) {
 
 int pmd_bg_project_impl(pmd_ctx* ctx, const float* xs, long D, int T, long ld, const float* basis, int K, float* out,
                         long ldo, void* ws, size_t ws_bytes) {
-  if (K < 1 || K > 64) return pmd_fail(ctx, PMD_ERR_UNSUPPORTED, "pmd_bg_project", "background rank must be in [1, 64]");
+  if (K < 1) return pmd_fail(ctx, PMD_ERR_ARG, "pmd_bg_project", "background rank must be >= 1");
   const int nblk = (int)((D + BGP_BLK - 1) / BGP_BLK);
   const long ldt = pmd_time_ld(T);
   pmd_arena ar(ws, ws_bytes);
   float* At = ar.take_n<float>((size_t)nblk * 64 * BGP_BLK);
   float* part = ar.take_n<float>((size_t)nblk * 64 * ldt);
   if (ar.overflow) return pmd_fail(ctx, PMD_ERR_WORKSPACE, "pmd_bg_project", "workspace too small");
-  hipLaunchKernelGGL(block_basis_kernel, dim3(nblk * (BGP_BLK / 256)), dim3(256), 0, ctx->stream, basis, D, K, At);
-  PMD_LAUNCH_CHECK(ctx, "block_basis_kernel");
-  RUN(pmd_launch_tile_atx(ctx, xs, ld, nullptr, 0, BGP_BLK, BGP_BLK, At, 64L * BGP_BLK, BGP_BLK, part, 64L * ldt, ldt, nblk, T, 8));
-  // sum the block partials row by row into out[k][0:T]
-  for (int k = 0; k < K; ++k)
-    RUN(pmd_launch_reduce_slices(ctx, part + (long)k * ldt, 0, 64L * ldt, nblk, T, out + (long)k * ldo, 0, 1));
+  // 64 basis columns per pass over the movie (ranks above 64: several passes)
+  for (int k0 = 0; k0 < K; k0 += 64) {
+    const int kc = (K - k0 < 64) ? K - k0 : 64;
+    hipLaunchKernelGGL(block_basis_kernel, dim3(nblk * (BGP_BLK / 256)), dim3(256), 0, ctx->stream, basis + k0, D, kc, At, K);
+    PMD_LAUNCH_CHECK(ctx, "block_basis_kernel");
+    RUN(pmd_launch_tile_atx(ctx, xs, ld, nullptr, 0, BGP_BLK, BGP_BLK, At, 64L * BGP_BLK, BGP_BLK, part, 64L * ldt, ldt, nblk, T, 8));
+    // sum the block partials row by row into out[k][0:T]
+    for (int k = 0; k < kc; ++k)
+      RUN(pmd_launch_reduce_slices(ctx, part + (long)k * ldt, 0, 64L * ldt, nblk, T, out + (long)(k0 + k) * ldo, 0, 1));
+  }
   return PMD_OK;
 }
 
@@ -773,7 +777,7 @@ __global__ __launch_bounds__(256) void gram_bg_blocks_kernel(const float* __rest
                                                              const float* __restrict__ basis, int K,
                                                              const int* __restrict__ col_off,
                                                              const int* __restrict__ ranks, float* __restrict__ Gbg,
-                                                             float* __restrict__ Gstrip, long ldgs) {
+                                                             float* __restrict__ Gstrip, long ldgs, int kstride) {
   const int tile = blockIdx.x;
   const int rk = ranks[tile];
   const long off = col_off[tile];
@@ -783,7 +787,7 @@ __global__ __launch_bounds__(256) void gram_bg_blocks_kernel(const float* __rest
     if (c < rk && k < K) {
       double s = 0.0;
       for (int q = 0; q < d; ++q)
-        s += (double)Uw[(long)tile * 64 * dpad + (long)c * dpad + q] * (double)basis[(long)pix[(long)tile * d + q] * K + k];
+        s += (double)Uw[(long)tile * 64 * dpad + (long)c * dpad + q] * (double)basis[(long)pix[(long)tile * d + q] * kstride + k];
       v = (float)s;
       Gstrip[(long)k * ldgs + off + c] = v;
     }
@@ -966,9 +970,13 @@ int pmd_gram_blocks_impl(pmd_ctx* ctx, const float* Uw, int dpad, int b1, int b2
   }
   if (K > 0) {
     PMD_HIP(ctx, hipMemsetAsync(Gstrip, 0, (size_t)K * ldgs * sizeof(float), ctx->stream));
-    hipLaunchKernelGGL(gram_bg_blocks_kernel, dim3(n_tiles), dim3(256), 0, ctx->stream, Uw, dpad, b1 * b2, pix, basis, K,
-                       col_off, ranks, Gbg, Gstrip, ldgs);
-    PMD_LAUNCH_CHECK(ctx, "gram_bg_blocks_kernel");
+    // Gbg: [K block of 64][tile][64][64] (one block of 64 background columns per launch)
+    for (int k0 = 0; k0 < K; k0 += 64) {
+      const int kc = (K - k0 < 64) ? K - k0 : 64;
+      hipLaunchKernelGGL(gram_bg_blocks_kernel, dim3(n_tiles), dim3(256), 0, ctx->stream, Uw, dpad, b1 * b2, pix, basis + k0, kc,
+                         col_off, ranks, Gbg + (long)(k0 / 64) * n_tiles * 4096, Gstrip + (long)k0 * ldgs, ldgs, K);
+      PMD_LAUNCH_CHECK(ctx, "gram_bg_blocks_kernel");
+    }
     hipLaunchKernelGGL(gram_bgbg_strip_kernel, dim3(K, K), dim3(256), 0, ctx->stream, basis, D, K, Rt, Gstrip, ldgs);
     PMD_LAUNCH_CHECK(ctx, "gram_bgbg_strip_kernel");
   }

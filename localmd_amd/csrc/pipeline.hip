@@ -646,7 +646,7 @@ static int background_rsvd_wide(pmd_ctx* ctx, const bg_plan& p, const float* xs,
 int pmd_background_rsvd_impl(pmd_ctx* ctx, const float* xs, long D, int n, long ld, int K, uint64_t seed,
                              float* basis_out, void* ws, size_t ws_bytes) {
   const int l = K + 10;
-  if (K < 1 || K > 64) return pmd_fail(ctx, PMD_ERR_UNSUPPORTED, "pmd_background_rsvd", "background_rank must be in [1, 64]");
+  if (K < 1 || l > 1024) return pmd_fail(ctx, PMD_ERR_UNSUPPORTED, "pmd_background_rsvd", "background_rank must be in [1, 1014]");
   if (ld < pmd_time_ld(n)) return pmd_fail(ctx, PMD_ERR_ARG, "pmd_background_rsvd", "leading dimension too small");
   pmd_arena ar(ws, ws_bytes);
   bg_plan p;

@@ -255,7 +255,7 @@ template <int KMAX>
 // thread reads and writes only its own column, and the clamped loads of the padding threads are discarded.
 __global__ __launch_bounds__(256) void filter_kernel(const float* in, float* out, long D,
                                                      int nf, long ld, const float* __restrict__ basis, int K,
-                                                     const float* __restrict__ pj, long ldp) {
+                                                     const float* __restrict__ pj, long ldp, int kstride) {
   const long f = (long)blockIdx.x * 256 + threadIdx.x;
   const long c0 = (long)blockIdx.y * 64;
   const bool live = f < nf;
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void filter_kernel(const float* in, float* out
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const long cu = (c + u < c1) ? c + u : c1 - 1;
-      const float* b = basis + cu * K;
+      const float* b = basis + cu * kstride;
       float acc = 0.f;
 #pragma unroll
       for (int k = 0; k < KMAX; ++k) acc = fmaf(b[(k < K) ? k : 0], p[k], acc);
@@ -288,19 +288,24 @@ __global__ __launch_bounds__(256) void filter_kernel(const float* in, float* out
 int pmd_launch_filter(pmd_ctx* ctx, const float* in, float* out, long D, int nf, long ld, const float* basis, int K,
                       const float* pj, long ldp) {
   pmd_prof_scope prof__(ctx, "bg_filter");
-  if (K > 64) return pmd_fail(ctx, PMD_ERR_UNSUPPORTED, "pmd_filter", "background rank > 64");
   const int bx = (int)((ld + 255) / 256);
   const long rows_per_launch = 65535L * 64;
-  for (long c0 = 0; c0 < D; c0 += rows_per_launch) {
-    const long cn = (D - c0 < rows_per_launch) ? D - c0 : rows_per_launch;
-    dim3 grid(bx, (unsigned)((cn + 63) / 64));
-    if (K <= 16)
-      hipLaunchKernelGGL(filter_kernel<16>, grid, dim3(256), 0, ctx->stream, in + c0 * ld, out + c0 * ld, cn, nf, ld,
-                         basis + c0 * K, K, pj, ldp);
-    else
-      hipLaunchKernelGGL(filter_kernel<64>, grid, dim3(256), 0, ctx->stream, in + c0 * ld, out + c0 * ld, cn, nf, ld,
-                         basis + c0 * K, K, pj, ldp);
-    PMD_LAUNCH_CHECK(ctx, "filter_kernel");
+  // background ranks above 64: blocks of 64 basis columns, each one more in-place pass X <- X - B_blk (B_blk^T X) (the
+  // projections pj were all formed from the unfiltered X, and the passes add up)
+  for (int k0 = 0; k0 < K; k0 += 64) {
+    const int kc = (K - k0 < 64) ? K - k0 : 64;
+    const float* src = (k0 == 0) ? in : out;
+    for (long c0 = 0; c0 < D; c0 += rows_per_launch) {
+      const long cn = (D - c0 < rows_per_launch) ? D - c0 : rows_per_launch;
+      dim3 grid(bx, (unsigned)((cn + 63) / 64));
+      if (kc <= 16)
+        hipLaunchKernelGGL(filter_kernel<16>, grid, dim3(256), 0, ctx->stream, src + c0 * ld, out + c0 * ld, cn, nf, ld,
+                           basis + c0 * K + k0, kc, pj + (long)k0 * ldp, ldp, K);
+      else
+        hipLaunchKernelGGL(filter_kernel<64>, grid, dim3(256), 0, ctx->stream, src + c0 * ld, out + c0 * ld, cn, nf, ld,
+                           basis + c0 * K + k0, kc, pj + (long)k0 * ldp, ldp, K);
+      PMD_LAUNCH_CHECK(ctx, "filter_kernel");
+    }
   }
   return PMD_OK;
 }

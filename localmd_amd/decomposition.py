@@ -503,8 +503,6 @@ def localmd_decomposition(
 
         t0 = time.perf_counter()
         K = int(background_rank)
-        if K > 64:
-            raise ValueError("background_rank must be <= 64 in the HIP pipeline (got {})".format(K))
         basis_dev = None
         if K > 0:
             sample = dist.broadcast_object(np.random.choice(list(range(T)), replace=False, size=min(1000, T)).tolist())
@@ -955,7 +953,7 @@ def localmd_decomposition(
             # P = right E / sqrt(lambda) stays factored; G = U^T U stays block-sparse
             n_pairs = pairs.shape[0]
             gblk = torch.empty((max(n_pairs, 1), 64, 64), dtype=torch.float32, device=ctx.device)
-            gbg = torch.zeros((n_tiles, 64, 64), dtype=torch.float32, device=ctx.device)
+            gbg = torch.zeros((max(1, (max(K, 0) + 63) // 64) * n_tiles, 64, 64), dtype=torch.float32, device=ctx.device)
             gstrip = torch.zeros((max(K, 1), Rc), dtype=torch.float32, device=ctx.device)
             ctx.call("pmd_gram_blocks", ptr(uw_dev), dpad, b1, b2, ptr(pix_dev), ptr(pairs_dev), n_pairs, ptr(origins_dev),
                      ptr(col_off_dev), ptr(ranks_dev), n_tiles, Rt, ptr(basis_dev), D, max(K, 0), ptr(gblk), ptr(gbg),

@@ -219,16 +219,19 @@ def neighbour_lists(pairs, ranks, col_off, n_tiles, Rt, K):
     cols = np.concatenate([b, a[off_diag]])
     blk = np.concatenate([idx, idx[off_diag]])
     flg = np.concatenate([np.zeros(len(a), dtype=np.int64), np.ones(int(off_diag.sum()), dtype=np.int64)])
-    if K > 0:
+    # background blocks: one per tile and per block of 64 background columns (column index -1 - kb keeps them apart from the
+    # tile columns and in block order); block index = kb * n_tiles + tile, as pmd_gram_blocks lays them out
+    for kb in range((max(K, 0) + 63) // 64):
         t = np.arange(n_tiles, dtype=np.int64)
         rows = np.concatenate([rows, t])
-        cols = np.concatenate([cols, np.full(n_tiles, -1, dtype=np.int64)])
-        blk = np.concatenate([blk, t])
+        cols = np.concatenate([cols, np.full(n_tiles, -1 - kb, dtype=np.int64)])
+        blk = np.concatenate([blk, kb * n_tiles + t])
         flg = np.concatenate([flg, np.full(n_tiles, 2, dtype=np.int64)])
     order = np.lexsort((cols, rows))
     rows, cols, blk, flg = rows[order], cols[order], blk[order], flg[order]
-    row0 = np.where(cols >= 0, np.asarray(col_off)[np.maximum(cols, 0)], Rt)
-    nrow = np.where(cols >= 0, np.asarray(ranks)[np.maximum(cols, 0)], K)
+    kb_of = np.maximum(-1 - cols, 0)
+    row0 = np.where(cols >= 0, np.asarray(col_off)[np.maximum(cols, 0)], Rt + 64 * kb_of)
+    nrow = np.where(cols >= 0, np.asarray(ranks)[np.maximum(cols, 0)], np.minimum(64, K - 64 * kb_of))
     nbr = np.stack([row0, nrow, blk, flg], axis=1).astype(np.int32)
     ptr = np.zeros(n_tiles + 1, dtype=np.int64)
     np.add.at(ptr, rows + 1, 1)

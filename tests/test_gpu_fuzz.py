@@ -100,8 +100,8 @@ def draw_option_cases(n_cases, seed):
 
 
 def draw_widecomp_cases(n_cases, seed):
-    """Draws on the generic-width tile path (round 3): max_components 55 ... 110 (128-row tiles), background_rank up to 64
-    (generic-width background rSVD above 54), with the other options of draw_option_cases - residual windows, rank_prune,
+    """Draws on the generic-width tile path (round 3): max_components 55 ... 110 (128-row tiles), background_rank up to 90
+    (generic-width background rSVD above 54, blocks of 64 background columns above 64), with the other options of draw_option_cases - residual windows, rank_prune,
     pixel weights, both pixel orders, several consecutive failures (which is what lets a tile keep more than 64 components)."""
     rng = np.random.default_rng(seed)
     out = []
@@ -116,7 +116,7 @@ def draw_widecomp_cases(n_cases, seed):
         pooled = (-(-b1 // saf)) * (-(-b2 // saf))
         r_max = min(110, frames // taf - 1, max(56, pooled))
         r = int(rng.integers(55, max(56, r_max) + 1))
-        kw = dict(max_components=r, background_rank=int(rng.choice([0, 3, 15, 40, 58, 64])),
+        kw = dict(max_components=r, background_rank=int(rng.choice([0, 3, 15, 40, 58, 90])),
                   temporal_avg_factor=taf, spatial_avg_factor=saf, order=str(rng.choice(["F", "C"])),
                   max_consecutive_failures=int(rng.choice([1, 1, 3, 100])))
         if rng.random() < 0.25:
@@ -362,7 +362,7 @@ _OPTION = {(sd, c[0]): c for sd in (21, 22, 23) for c in draw_option_cases(48, s
 
 
 # the generic-width family (round 3; 28 draws swept over two seeds).  Seed 1: draw 0 = max_components 108 with residual windows
-# and background_rank 64; draw 1 = every component of 30 x 28-pixel tiles kept (max_consecutive_failures 100, 88 components,
+# and background_rank 90; draw 1 = every component of 30 x 28-pixel tiles kept (max_consecutive_failures 100, 88 components,
 # two blocks of 64 rows per tile in the global stage), R > frames in the unresolvable regime - the draw that showed the
 # double-precision eigenvalue paths amplifying null directions beyond anything the reference's fp32 arithmetic does;
 # draw 4 = rank_prune with 84 components and 58 background columns, C order; draw 10 = pixel weights + windows at 109.

@@ -348,6 +348,22 @@ def test_full_pipeline_background_rank_60(gpu_ctx):
     _check_full(pmd, diag, ref, mov, vt_tol=3e-3)
 
 
+def test_full_pipeline_background_rank_100(gpu_ctx):
+    """background_rank above 64 (unbounded in the reference, pmd_loader.py:300-314): the filter, the projection and the
+    background blocks of U^T U run in blocks of 64 background columns.  First with R <= frames (dense U^T U), then with
+    R > frames (block-sparse U^T U with two background blocks per tile)."""
+    mov = _movie(1000, 60, 60, seed=41)
+    pmd, diag, ref = _compare_full(gpu_ctx, mov, (20, 20), 1000, max_components=6, background_rank=100, sim_iters=10)
+    assert pmd.u.shape[1] == int(diag["tile_ranks"].sum()) + 100 and diag["rank_before"] <= diag["crop"]
+    # (the comparison counts every background column as a "stable" column of U; with 70-100 of them the last ones are
+    # noise-level singular vectors of the 1000-frame sample with gaps of a few per cent: u_tol 2e-3 instead of 5e-4)
+    _check_full(pmd, diag, ref, mov, vt_tol=3e-3, u_tol=2e-3)
+    mov = _movie(300, 70, 80, seed=42)
+    pmd, diag, ref = _compare_full(gpu_ctx, mov, (10, 10), 300, max_components=8, background_rank=70, sim_iters=10)
+    assert diag["rank_before"] > diag["crop"]
+    _check_full(pmd, diag, ref, mov, vt_tol=5e-3, orth_tol=1e-2, s_tol=3e-3, vt_tol_signal=2e-3, probe_tol=5e-3, u_tol=2e-3)
+
+
 def test_full_pipeline_subsampled_frames_and_no_background(gpu_ctx):
     mov = _movie(900, 36, 44, seed=2)
     pmd, diag, ref = _compare_full(gpu_ctx, mov, (16, 20), 300, max_components=5, background_rank=0, sim_iters=10)
