@@ -5,8 +5,8 @@
 #include <algorithm>
 
 int pmd_tile_dpad(int d) {
-  if (d > 2048) return -1;
-  if (d > 1024) return 2048;
+  if (d > 65536) return -1;
+  if (d > 1024) return (int)pmd_round_up(d, 1024);   // tile_atx splits the pixel axis over the grid in slices of 1024
   pmd_dvariant v;
   if (!pmd_pick_dvariant(d, &v)) return -1;
   return v.dpad;
@@ -189,7 +189,7 @@ int pmd_tiles_decompose_impl(pmd_ctx* ctx, const float* Xf, long ldx, long n_row
   pmd_arena ar(ws, ws_bytes);
   tiles_plan p;
   if (plan_tiles(ar, p, n, d, P, r, a, t_crop, ldv, n_rows) != PMD_OK)
-    return pmd_fail(ctx, PMD_ERR_UNSUPPORTED, "pmd_tiles_decompose", "tile too large (max 2048 pixels)");
+    return pmd_fail(ctx, PMD_ERR_UNSUPPORTED, "pmd_tiles_decompose", "tile too large (max 65536 pixels)");
   if (ar.overflow) return pmd_fail(ctx, PMD_ERR_WORKSPACE, "pmd_tiles_decompose", "workspace too small");
   // max_components beyond the number of time bins or of pooled pixels: the reference's rSVD (decomposition.py:59-73) keeps
   // its sketch of max_components + 10 columns and `u_final[:, :rank]` simply returns the min(rank, bins, pixels) columns

@@ -359,8 +359,7 @@ int pmd_launch_tile_atx(pmd_ctx* ctx, const float* X, long ldx, const int* pix, 
   int kz = 1;
   int dv = d;
   if (d > 1024) {
-    if (d > 2048) return pmd_fail(ctx, PMD_ERR_UNSUPPORTED, "tile_atx", "tile larger than 2048 pixels");
-    kz = 2;
+    kz = (d + 1023) / 1024;    // grid-level K split: slice z covers pixels [1024 z, 1024 (z + 1)), partial sums by atomicAdd
     dv = 1024;
     // the two K halves accumulate with atomics: clear the 64 output rows of every tile (only those: the tile stride may
     // cover more row blocks than this call writes, pmd_launch_tile_atx_rp)

@@ -637,7 +637,7 @@ def localmd_decomposition(
         P_pool = pool_q.shape[0]
         dpad = lib.pmd_tile_dpad(d)
         if dpad < 0 or lib.pmd_tile_dpad(P_pool) < 0:
-            raise ValueError("block of {} x {} pixels is larger than the supported maximum (2048 pixels)".format(b1, b2))
+            raise ValueError("block of {} x {} pixels is larger than the supported maximum (65536 pixels)".format(b1, b2))
         # Component rows of the per-tile arrays: 64 while max_components + 10 <= 64 (the MFMA-tiled kernels), a larger multiple
         # of 64 beyond (generic-width kernels, csrc/wide.hip) - max_components is unbounded, as in the reference
         # (decomposition.py:643-665).  The global stage works on blocks of 64 component rows: an array with rpad = 64 nvt rows is

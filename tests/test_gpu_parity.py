@@ -364,6 +364,15 @@ def test_full_pipeline_background_rank_100(gpu_ctx):
     _check_full(pmd, diag, ref, mov, vt_tol=5e-3, orth_tol=1e-2, s_tol=3e-3, vt_tol_signal=2e-3, probe_tol=5e-3, u_tol=2e-3)
 
 
+def test_full_pipeline_tiles_above_2048_pixels(gpu_ctx):
+    """48 x 50-pixel blocks (2400 pixels; the reference accepts any even block size >= 10, decomposition.py:572-613): the tile
+    contractions split the pixel axis over the grid in slices of 1024 (three slices here), pooled tiles of 600 pixels."""
+    mov = _movie(600, 96, 100, seed=43)
+    pmd, diag, ref = _compare_full(gpu_ctx, mov, (48, 50), 600, max_components=8, background_rank=3, sim_iters=10)
+    assert diag["dpad"] == 3072 and len(diag["tile_ranks"]) == 9
+    _check_full(pmd, diag, ref, mov, vt_tol=3e-3)
+
+
 def test_full_pipeline_subsampled_frames_and_no_background(gpu_ctx):
     mov = _movie(900, 36, 44, seed=2)
     pmd, diag, ref = _compare_full(gpu_ctx, mov, (16, 20), 300, max_components=5, background_rank=0, sim_iters=10)

@@ -465,7 +465,7 @@ def test_library_exports_every_declared_symbol():
     assert loaded.pmd_version() == 1
     # host-only helpers can be called without a device
     assert loaded.pmd_tile_dpad(400) == 400 and loaded.pmd_tile_dpad(100) == 256 and loaded.pmd_tile_dpad(1024) == 1024
-    assert loaded.pmd_tile_dpad(1600) == 2048 and loaded.pmd_tile_dpad(3000) == -1
+    assert loaded.pmd_tile_dpad(1600) == 2048 and loaded.pmd_tile_dpad(3000) == 3072 and loaded.pmd_tile_dpad(70000) == -1
     assert loaded.pmd_time_ld(10000) == 10048 + 64 and loaded.pmd_time_ld(64) == 128
     assert loaded.pmd_tiles_workspace_bytes(2601, 20, 20, 100, 50, 10, 10000, 10112, 262144) > 0
 
