@@ -1383,7 +1383,14 @@ int pmd_gram_mtgm_impl(pmd_ctx* ctx, const float* M, int rows, int m, long ldm, 
 // in fp64 and rounded).  The Cholesky route amplifies the factorisation error by the condition number of C, which the
 // reference's rank_prune and R > frames routes drive to 1e5 ... 1e7: in fp32 the signal singular values of such draws came
 // out 27 % off where NumPy's (double-precision LAPACK on fp32 data) are 2 % off (seeded fuzz, options 104 / 42).
-static const int CHOL_F64_MAX = 512;
+// Orders up to which the Cholesky step runs in double precision (rocSOLVER dpotrf + dtrtri on a widened copy, results
+// rounded).  PMD_CHOL_F64_MAX overrides.
+static int chol_f64_max() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("PMD_CHOL_F64_MAX"); v = e ? atoi(e) : 512; }
+  return v;
+}
+#define CHOL_F64_MAX chol_f64_max()
 
 namespace {
 __global__ void chol_widen_kernel(const float* __restrict__ src, long lds_, double* __restrict__ dst, long ldd, int n) {

@@ -1073,7 +1073,16 @@ def localmd_decomposition(
                         piv = 1.0 / max(float(Et_dev[m_eff - 1, m_eff - 1].item()) ** 2, 1e-300)
                         null_pivot_rel = piv / max(float(tr_c_dev.item()) / m_eff, 1e-300)
                         null_info["pivot_rel"] = null_pivot_rel
-                    if abs_last and null_pivot_rel <= NULL_PIVOT_REL:
+                        # The pivot of a null direction is rounding noise and can come out accidentally tiny (3e-12 of the mean
+                        # diagonal seen: the kept direction was then scaled up 5e5 times and led the spectrum with 18 x s_1).
+                        # The reference's fp32 eigensolver returns |lambda| ~ eps32 lambda_max for such a direction, never less:
+                        # the pivot is floored at eps32 trace(C) / 4 (lambda_max <= trace), which bounds the amplification the
+                        # same way (the last row of Et is linear in 1 / sqrt(pivot)).
+                        floor_rel = 1.1920929e-07 * m_eff / 4.0
+                        null_info["pivot_floor_rel"] = floor_rel
+                        if null_pivot_rel < floor_rel:
+                            Et_dev[m_eff - 1, :m_eff] *= math.sqrt(null_pivot_rel / floor_rel)
+                    if abs_last and null_pivot_rel <= max(NULL_PIVOT_REL, 8.0 * floor_rel):
                         # The last row of Et is the kept numerically null direction (scale 1 / sqrt(|last pivot|), as the
                         # reference's 1 / sqrt(|lambda|), decomposition.py:984-996).  Its coupling to the other directions is
                         # rounding noise, so it is carried as one extra component next to the SVD of the leading

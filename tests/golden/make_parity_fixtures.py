@@ -5,7 +5,8 @@ the HOST Philox source (oracle/philox.py), so that the GPU box compares the HIP 
 running minutes of oracle:
 
     python tests/golden/make_parity_fixtures.py rle        # 128 x 128 x 10000, R <= frames: eigenvector route
-    python tests/golden/make_parity_fixtures.py headline   # 256 x 256 x 10000, R > frames: the regime bench.py times
+    python tests/golden/make_parity_fixtures.py headline   # 352 x 352 x 10000, R > frames: the regime bench.py times
+    python tests/golden/make_parity_fixtures.py headline-single   # appends the distances of the single-precision-LAPACK oracle
 
 Each fixture holds two referees: the fp32 oracle (the reference's arithmetic up to LAPACK rounding) and the float64
 arbiter (the exact result of the reference's algorithm on the same inputs).  The movies carry a ladder of bright sources
@@ -68,6 +69,46 @@ def main(name):
     print("wrote", path, os.path.getsize(path), "bytes")
 
 
+def add_single_lapack_distances(name):
+    """Third referee, distances only: the oracle with TRUE single-precision LAPACK (scipy's s-routines: the arithmetic jaxlib's
+    CPU kernels run the reference in) against the float64 arbiter already in the fixture, on the arbiter's signal components.
+    Appended to the .npz as ref32s_*: what the reference's own arithmetic loses in this regime, the yardstick for the HIP path."""
+    path = os.path.join(HERE, f"parity_{name}.npz")
+    g = dict(np.load(path, allow_pickle=False))
+    c = CASES[name]
+    mov = case_movie(c)
+    O.LAPACK_PRECISION = "single"
+    t0 = time.perf_counter()
+    try:
+        np.random.seed(c["np_seed"])
+        res = O.localmd_decomposition(mov, (c["block"], c["block"]), c["T"], max_components=c["max_components"],
+                                      rng=philox.PhiloxSource(c["seed"]), thresholds=tuple(g["f32_thresholds"]))
+    finally:
+        O.LAPACK_PRECISION = "double"
+    sig = g["f64_signal"].astype(np.int64)
+    s_b = g["f64_s"].astype(np.float64)
+    g["ref32s_tile_ranks_equal"] = np.array(np.array_equal(res.diag["tile_ranks"], g["f64_tile_ranks"]))
+    g["ref32s_s_rel_signal"] = np.abs(np.asarray(res.s, np.float64)[sig] - s_b[sig]) / s_b[sig]
+    va, vb = np.asarray(res.v[sig], np.float64), g["f64_Vt_signal"].astype(np.float64)
+    sgn = np.where(np.sum(va * vb, axis=1) < 0, -1.0, 1.0)
+    g["ref32s_vt_row_err"] = np.linalg.norm(va * sgn[:, None] - vb, axis=1) / np.linalg.norm(vb, axis=1)
+    u = res.u.tocsr()
+    pix = g["f64_pix_sample"].astype(np.int64)
+    ur = np.asarray(u[pix] @ np.asarray(res.r[:, sig], np.float64)) * sgn[None, :]
+    urb = g["f64_UR_signal_sample"].astype(np.float64)
+    g["ref32s_ur_col_err"] = np.linalg.norm(ur - urb, axis=0) / np.linalg.norm(urb, axis=0)
+    pi, pt = g["f64_probe_pix"].astype(np.int64), g["f64_probe_frame"].astype(np.int64)
+    rec = np.einsum("pk,k,kp->p", np.asarray(u[pi] @ res.r), res.s, res.v[:, pt])
+    g["ref32s_probes"] = np.array(np.abs(rec - g["f64_probe_rec"]).max() / np.abs(g["f64_probe_rec"]).max())
+    print(f"{name} single-LAPACK oracle: {time.perf_counter() - t0:.0f} s; vs arbiter: s {g['ref32s_s_rel_signal'].max():.2e}, "
+          f"Vt rows {g['ref32s_vt_row_err'].max():.2e}, (U R) {g['ref32s_ur_col_err'].max():.2e}, probes {float(g['ref32s_probes']):.2e}, "
+          f"tile ranks equal {bool(g['ref32s_tile_ranks_equal'])}", flush=True)
+    np.savez_compressed(path, **g)
+
+
 if __name__ == "__main__":
     for nm in sys.argv[1:] or ["rle"]:
-        main(nm)
+        if nm.endswith("-single"):
+            add_single_lapack_distances(nm[:-7])
+        else:
+            main(nm)

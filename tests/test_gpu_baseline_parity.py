@@ -140,27 +140,40 @@ def test_r_le_frames_at_scale_meets_the_north_star_vt_tolerance(gpu_ctx):
 
 
 def test_headline_regime_parity(gpu_ctx):
-    """T = 10^4 frames, 50 components per tile, 625 tiles of a 256 x 256 field of view: R ~ 14 000 > frames, the Cholesky route
+    """T = 10^4 frames, 50 components per tile, 1156 tiles of a 352 x 352 field of view: R = 17 327 > frames, the Cholesky route
     and the library's own eigensolver at order 10^4 - the regime that dominates bench.py - against the committed fixture
-    (fp32 oracle and float64 arbiter, generated once in the build container: 10 + 15 minutes of CPU).  The movie carries a
-    ladder of 28 bright band-limited sources, so >= 20 leading components have separated singular values and can be
-    compared one by one."""
+    (fp32 oracle and float64 arbiter, generated once in the build container: 15 + 22 minutes of CPU; plus the distances of
+    the single-precision-LAPACK oracle to the arbiter, the reference's own arithmetic).  The movie carries a ladder of 28
+    bright band-limited sources: 25 leading components with singular values separated by more than 2 % are compared one by
+    one.  Measured (round 3): vs the arbiter s 1.1e-4, Vt rows 1.1e-3 (median 2.2e-4), (U R) 7.4e-2, R 3.7e-3 of 0.86; the
+    NumPy oracle (double-precision LAPACK on fp32 data) sits at 2.8e-5 / 2.9e-4 / 1.4e-2 from the arbiter."""
     out, diag = _run_fixture_case(gpu_ctx, "headline")
     assert diag["rank_before"] > diag["crop"] == 10000 and diag["orthogonalizer"] == "cholesky"
+    assert diag["null_direction"]["split_off"]
     for ref in ("f32", "f64"):
         m = out[ref]
         _assert_structure(m)
         assert m["n_signal"] >= 20, m["n_signal"]
-        assert m["u_data_err_stable"] < 1e-3 * m["u_data_max_abs"] and m["n_stable_cols_compared"] >= 32
+        assert m["u_data_err_stable"] < 1e-4 * m["u_data_max_abs"] and m["n_stable_cols_compared"] >= 32
     mo, ma = out["f32"], out["f64"]
     # against the exact result of the reference's algorithm (float64 arbiter)
-    assert ma["s_rel_signal"] < 2e-4 and ma["vt_row_err"].max() < 2e-3 and ma["ur_col_err"].max() < 2e-2, \
-        (ma["s_rel_signal"], ma["vt_row_err"].max(), ma["ur_col_err"].max())
-    assert ma["probes"] < 2e-2
+    assert ma["s_rel_signal"] < 3e-4 and ma["vt_row_err"].max() < 3e-3 and np.median(ma["vt_row_err"]) < 6e-4, \
+        (ma["s_rel_signal"], ma["vt_row_err"].max(), np.median(ma["vt_row_err"]))
+    assert ma["ur_col_err"].max() < 1.5e-1 and ma["r_err_stable_signal"] < 1e-2 * ma["r_max_abs"], (ma["ur_col_err"].max(), ma["r_err_stable_signal"])
+    assert ma["probes"] < 5e-2, ma["probes"]
     # against the fp32 oracle (whose own distance to the arbiter is part of the figure in this regime, DESIGN section 2)
-    assert mo["s_rel_signal"] < 2e-3 and mo["vt_row_err"].max() < 3e-3 and mo["ur_col_err"].max() < 5e-2, \
+    assert mo["s_rel_signal"] < 3e-4 and mo["vt_row_err"].max() < 3e-3 and mo["ur_col_err"].max() < 1.5e-1, \
         (mo["s_rel_signal"], mo["vt_row_err"].max(), mo["ur_col_err"].max())
-    assert mo["probes"] < 4e-2
+    assert mo["probes"] < 5e-2, mo["probes"]
+    # against the reference's own arithmetic (single-precision LAPACK), when its distances are in the fixture: the HIP path is
+    # not farther from the arbiter than 1.5 x that
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "parity_headline.npz"), allow_pickle=False)
+    if "ref32s_vt_row_err" in g.files:
+        print("single-precision-LAPACK oracle vs arbiter: s %.2e, Vt rows %.2e, (U R) %.2e, probes %.2e" % (
+            g["ref32s_s_rel_signal"].max(), g["ref32s_vt_row_err"].max(), g["ref32s_ur_col_err"].max(), float(g["ref32s_probes"])))
+        assert ma["vt_row_err"].max() <= 1.5 * g["ref32s_vt_row_err"].max() + 1e-4
+        assert ma["s_rel_signal"] <= 1.5 * g["ref32s_s_rel_signal"].max() + 1e-4
+        assert ma["ur_col_err"].max() <= 1.5 * g["ref32s_ur_col_err"].max() + 1e-4
 
 
 def test_hip_path_reproduces_committed_golden_fixture(gpu_ctx):
