@@ -446,7 +446,13 @@ def test_orthogonalizer_variants_agree(gpu_ctx):
     strong = a.s[:n] > 5e-2 * a.s[0]
     np.testing.assert_allclose(b.s[:n][strong], a.s[:n][strong], rtol=2e-3)
     ura, urb = a.u @ a.r, b.u @ b.r
-    assert np.abs(urb.T @ urb - np.eye(urb.shape[1])).max() < 1e-2
+    eb = urb.T @ urb - np.eye(urb.shape[1])
+    if db["null_direction"].get("split_off"):
+        # the kept numerically null direction (last component): its pivot is floored at the fp32 rounding level (as the
+        # reference's fp32 eigenvalue would be), so its column of U R has norm <= 1, not 1
+        assert -1.0 - 1e-6 <= eb[-1, -1] <= 1e-2
+        eb[-1, -1] = 0.0
+    assert np.abs(eb).max() < 1e-2
     rng = np.random.default_rng(0)
     pi, pt = rng.integers(0, 5600, 400), rng.integers(0, 300, 400)
     ra = np.einsum("pk,k,kp->p", ura[pi], a.s, a.v[:, pt])
