@@ -270,16 +270,16 @@ def main():
         import hashlib
 
         root = os.path.dirname(os.path.abspath(__file__))
-        pmc = json.load(open(os.path.join(root, "profiles", "r02_pmc_tile_atx.json")))
+        pmc = json.load(open(os.path.join(root, "profiles", "r03_pmc_tile_atx.json")))
         sha = hashlib.sha256(open(os.path.join(root, pmc["kernel_source"]), "rb").read()).hexdigest()
         if args.config != DEFAULT_CONFIG:
             roofline["traffic_note"] = "no counter pass for this workload"
         elif sha != pmc["kernel_source_sha256"]:
-            roofline["traffic_note"] = "stale: the kernel source changed since the counter pass (profiles/r02_pmc_tile_atx.json)"
+            roofline["traffic_note"] = "stale: the kernel source changed since the counter pass (profiles/r03_pmc_tile_atx.json)"
         else:
             roofline["traffic"] = pmc["fetch_bytes_per_launch"] / 1e9
             roofline["traffic_unit"] = "GB per launch (L2 -> fabric reads, Infinity Cache hits included)"
-            roofline["traffic_source"] = "profiles/r02_pmc_tile_atx.json (separate rocprofv3 --pmc FETCH_SIZE pass, gfx950 x2 correction)"
+            roofline["traffic_source"] = "profiles/r03_pmc_tile_atx.json (separate rocprofv3 --pmc FETCH_SIZE pass, gfx950 x2 correction)"
     except (OSError, KeyError, ValueError):
         roofline["traffic_note"] = "no committed counter pass found"
     roofline_mfma = roofline
@@ -311,17 +311,17 @@ def main():
             import hashlib
 
             root = os.path.dirname(os.path.abspath(__file__))
-            pmc = json.load(open(os.path.join(root, "profiles", "r02_pmc_sytrd_n10000.json")))
+            pmc = json.load(open(os.path.join(root, "profiles", "r03_pmc_sytrd_n10000.json")))
             sha = hashlib.sha256(open(os.path.join(root, pmc["kernel_source"]), "rb").read()).hexdigest()
             if abs(n_eig - pmc["matrix_order"]) > 1:
                 roofline["traffic_note"] = "no counter pass for a matrix of this order"
             elif sha != pmc["kernel_source_sha256"]:
-                roofline["traffic_note"] = "stale: the kernel source changed since the counter pass (profiles/r02_pmc_sytrd_n10000.json)"
+                roofline["traffic_note"] = "stale: the kernel source changed since the counter pass (profiles/r03_pmc_sytrd_n10000.json)"
             else:
                 roofline["traffic"] = pmc["traffic_bytes_per_launch_sample_mean"] / 1e9
                 roofline["traffic_unit"] = "GB per launch (L2 -> fabric reads, Infinity Cache hits included)"
                 roofline["traffic_over_algorithmic"] = pmc["traffic_over_algorithmic_sample"]
-                roofline["traffic_source"] = "profiles/r02_pmc_sytrd_n10000.json (separate rocprofv3 --pmc FETCH_SIZE pass, gfx950 x2 correction)"
+                roofline["traffic_source"] = "profiles/r03_pmc_sytrd_n10000.json (separate rocprofv3 --pmc FETCH_SIZE pass, gfx950 x2 correction)"
         except (OSError, KeyError, ValueError):
             roofline["traffic_note"] = "no committed counter pass found"
     out = {

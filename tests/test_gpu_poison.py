@@ -45,18 +45,17 @@ def _cases():
     out = []
     for name, seed, n, case in pick:
         c = [c for c in fam[name](n, seed) if c[0] == case][0]
-        out.append(pytest.param(c, id=f"{name}-{seed}-{case}"))
+        out.append(pytest.param(c, False, id=f"{name}-{seed}-{case}"))
+        if c[0] % 2 == 0:      # the threshold simulation on half of the draws
+            out.append(pytest.param(c, True, id=f"{name}-{seed}-{case}-simulated"))
     return out
 
 
-@pytest.mark.parametrize("c", _cases())
-@pytest.mark.parametrize("simulate", [False, True])
+@pytest.mark.parametrize("c,simulate", _cases())
 def test_results_do_not_depend_on_buffer_contents(gpu_ctx, c, simulate):
     import localmd_amd
     from localmd_amd import decomposition as Dm
 
-    if simulate and c[0] % 2:      # the threshold simulation on half of the draws
-        pytest.skip("simulation covered by the other half")
     case, T, d1, d2, b1, b2, frames, kw = c[:8]
     extra = c[8] if len(c) > 8 else {"noise": 1.0, "dtype": "float32"}
     mov = make_movie(T, d1, d2, seed=1000 + case, noise=extra["noise"])
