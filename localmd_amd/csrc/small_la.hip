@@ -270,6 +270,210 @@ __global__ __launch_bounds__(EIG_THREADS) void small_eig_kernel(const double* __
   if (tid < 64) lam_out[(long)blockIdx.x * 64 + tid] = (tid < n) ? A[order[tid] * EIG_LD + order[tid]] : 0.0;
 }
 
+// ---------------------------------------------------------------- tridiagonal QL eigensolver, one wave per problem ----
+// The same contract as small_eig_kernel (G summed over its slices and symmetrised on load; Nout / lam_out in descending
+// order; mode 1 scaling and null rule), by Householder tridiagonalisation (LAPACK dsytd2 'L' conventions), in-place
+// formation of Q (dorg2r on the shifted array, as dorgtr does) and the implicit QL iteration with the rotations
+// accumulated into Q (EISPACK tql2) - all in ONE wave on one n x (n + 1) fp64 array in LDS (29 KB at n = 60: five problems
+// share a CU; the Jacobi kernel above holds A and V, 66 KB, two per CU, and spends two 1024-thread barriers on every one
+// of its ~470 rotation steps).  The tridiagonal matrix lives in REGISTERS: lane i holds d[i], e[i], tau[i]; a scalar is
+// fetched with v_readlane and stored by a predicated move, so the dependent chain of a rotation is ~250 cycles of fp64
+// arithmetic with no memory access in it.  The accumulated rotations touch a lane's own row of Q only (no cross-lane
+// hazard in the whole QL phase), and the column two rotations share stays in a register.  Cross-lane traffic through LDS
+// exists only in the two Householder phases (reflector broadcast), fenced by single-wave barriers.
+__device__ __forceinline__ double pmd_readlane_f64(double v, int l) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), l);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+  return __hiloint2double(hi, lo);
+}
+
+__global__ __launch_bounds__(64) void small_eig_ql_kernel(const double* __restrict__ G, long g_tile_stride, int slices, int n,
+                                                          int mode, double tol, double* __restrict__ Nout,
+                                                          double* __restrict__ lam_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int LD = n + 1;
+  double* A = reinterpret_cast<double*>(smem);                 // [n][LD]; ends as the eigenvector matrix
+  double* vv = A + (size_t)n * LD;                             // [64] reflector
+  double* ww = vv + 64;                                        // [64]
+  int* order = reinterpret_cast<int*>(ww + 64);                // [64]
+  const int lane = threadIdx.x;
+  const double* g = G + (long)blockIdx.x * g_tile_stride;
+  for (int i = lane; i < n * n; i += 64) {
+    const int r = i / n, c = i - r * n;
+    double sm = 0.0;
+    for (int k = 0; k < slices; ++k) sm += g[(long)k * 4096 + r * 64 + c] + g[(long)k * 4096 + c * 64 + r];
+    A[r * LD + c] = 0.5 * sm;
+  }
+  auto wsum = [](double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+  };
+  double dreg = 0.0, ereg = 0.0, treg = 0.0;                   // d[lane], e[lane] (couples lane, lane + 1), tau[lane]
+  double* row = A + (size_t)(lane < n ? lane : 0) * LD;        // this lane's row (lanes >= n never store)
+  const bool live = lane < n;
+  // ---- Householder tridiagonalisation: A = Q T Q^T, reflector k in A[k+2.., k], tau[k]
+  for (int k = 0; k + 1 < n; ++k) {
+    __syncthreads();                                           // rows updated by the previous step are visible
+    const double alpha = A[(k + 1) * LD + k];
+    const double xi = (lane > k + 1 && live) ? row[k] : 0.0;
+    const double sigma = wsum(xi * xi);
+    if (lane == k) dreg = row[k];
+    if (sigma == 0.0) {
+      if (lane == k) { ereg = alpha; treg = 0.0; }
+      continue;
+    }
+    const double nrm = sqrt(alpha * alpha + sigma);
+    const double beta = (alpha >= 0.0) ? -nrm : nrm;
+    const double t = (beta - alpha) / beta;
+    const double scale = 1.0 / (alpha - beta);
+    const double vi = (lane == k + 1) ? 1.0 : xi * scale;     // zero for lane <= k and lane >= n
+    if (lane == k) { ereg = beta; treg = t; }
+    vv[lane] = vi;
+    if (lane > k + 1 && live) row[k] = vi;
+    __syncthreads();
+    // p = tau A22 v (row `lane` of the full symmetric trailing block)
+    double pi = 0.0;
+    if (lane > k && live) {
+      double p0 = 0.0, p1 = 0.0;
+      int j = k + 1;
+      for (; j + 1 < n; j += 2) { p0 = fma(row[j], vv[j], p0); p1 = fma(row[j + 1], vv[j + 1], p1); }
+      if (j < n) p0 = fma(row[j], vv[j], p0);
+      pi = (p0 + p1) * t;
+    }
+    const double a2 = -0.5 * t * wsum(pi * vi);
+    const double wi = pi + a2 * vi;
+    ww[lane] = wi;
+    __syncthreads();
+    if (lane > k && live)
+      for (int j = k + 1; j < n; ++j) row[j] -= vi * ww[j] + wi * vv[j];
+  }
+  if (lane == n - 1) { dreg = row[n - 1]; ereg = 0.0; }
+  __syncthreads();
+  // ---- Q in place.  B[i'][j'] = A[i' + 1][j'] (i', j' < m = n - 1) holds reflector k below its diagonal in column k:
+  //      dorg2r on B, then the columns move one to the right and row / column 0 become those of the unit matrix.
+  const int m = n - 1;
+  if (m >= 1) {
+    const int kr = m - 1;                                     // reflectors 0 .. kr - 1
+    double* B = A + LD;                                        // B(i, j) = B[i * LD + j]
+    if (lane < m)
+      for (int j = kr; j < m; ++j) B[lane * LD + j] = (lane == j) ? 1.0 : 0.0;   // columns kr .. m - 1 of the unit matrix
+    for (int i = kr - 1; i >= 0; --i) {
+      __syncthreads();
+      const double t = pmd_readlane_f64(treg, i);
+      // apply H(i) to B(i:m, i+1:m) from the left; lane = column j
+      if (lane > i && lane < m) {
+        double w0 = B[i * LD + lane], w1 = 0.0;                // v[i] = 1
+        int r = i + 1;
+        for (; r + 1 < m; r += 2) { w0 = fma(B[r * LD + i], B[r * LD + lane], w0); w1 = fma(B[(r + 1) * LD + i], B[(r + 1) * LD + lane], w1); }
+        if (r < m) w0 = fma(B[r * LD + i], B[r * LD + lane], w0);
+        const double wj = (w0 + w1) * t;
+        B[i * LD + lane] -= wj;
+        for (r = i + 1; r < m; ++r) B[r * LD + lane] -= wj * B[r * LD + i];
+      }
+      __syncthreads();
+      // column i becomes H(i) e_i (lane = row)
+      if (lane < m) {
+        const double vr = B[lane * LD + i];
+        B[lane * LD + i] = (lane < i) ? 0.0 : (lane == i) ? 1.0 - t : -t * vr;
+      }
+    }
+    __syncthreads();
+    // shift the columns one to the right (lane = row of A), unit first row and column
+    if (lane >= 1 && live) {
+      for (int j = m; j >= 1; --j) row[j] = row[j - 1];
+      row[0] = 0.0;
+    }
+    __syncthreads();
+    if (live) A[lane] = (lane == 0) ? 1.0 : 0.0;
+  } else if (lane == 0) {
+    A[0] = 1.0;
+  }
+  __syncthreads();
+  // ---- implicit QL with accumulated rotations (EISPACK tql2); e[i] couples i and i + 1, e[n-1] = 0.
+  //      From here on a lane touches its own row of A only.
+  {
+    double f = 0.0, tst1 = 0.0;
+    const double eps = 2.220446049250313e-16;
+    for (int l = 0; l < n; ++l) {
+      const double dl0 = pmd_readlane_f64(dreg, l), el0 = pmd_readlane_f64(ereg, l);
+      tst1 = fmax(tst1, fabs(dl0) + fabs(el0));
+      // first m >= l with a negligible e[m] (e[n-1] = 0 guarantees one)
+      const unsigned long long small = __ballot(live && lane >= l && !(fabs(ereg) > eps * tst1));
+      const int mm = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(small | (1ull << (n - 1))));
+      if (mm > l) {
+        int iter = 0;
+        double el = el0;
+        do {
+          ++iter;
+          double gg = pmd_readlane_f64(dreg, l);
+          const double dnext = pmd_readlane_f64(dreg, l + 1);
+          double p = (dnext - gg) / (2.0 * el);
+          double r = sqrt(p * p + 1.0);
+          if (p < 0.0) r = -r;
+          const double dl = el / (p + r);
+          const double dl1 = el * (p + r);
+          double h = gg - dl;
+          if (lane == l) dreg = dl;
+          else if (lane == l + 1) dreg = dl1;
+          else if (lane >= l + 2 && live) dreg -= h;
+          f += h;
+          p = pmd_readlane_f64(dreg, mm);
+          double c = 1.0, c2 = 1.0, c3 = 1.0, s_ = 0.0, s2 = 0.0;
+          const double el1 = pmd_readlane_f64(ereg, l + 1);
+          double zhi = live ? row[mm] : 0.0;                   // column i + 1 of this lane's row, carried between rotations
+          for (int i = mm - 1; i >= l; --i) {
+            const double zlo = live ? row[i] : 0.0;
+            c3 = c2;
+            c2 = c;
+            s2 = s_;
+            const double ei = pmd_readlane_f64(ereg, i), di = pmd_readlane_f64(dreg, i);
+            gg = c * ei;
+            h = c * p;
+            const double q2 = p * p + ei * ei;
+            const double rinv = (q2 > 0.0) ? rsqrt(q2) : 0.0;
+            const double enew = s_ * (q2 * rinv);
+            if (q2 > 0.0) { s_ = ei * rinv; c = p * rinv; }
+            else { s_ = 0.0; c = 1.0; }
+            p = c * di - s_ * gg;
+            const double dnew = h + s_ * (c * gg + s_ * di);
+            if (lane == i + 1) { ereg = enew; dreg = dnew; }
+            if (live) row[i + 1] = s_ * zlo + c * zhi;
+            zhi = c * zlo - s_ * zhi;
+          }
+          if (live) row[l] = zhi;
+          p = -s_ * s2 * c3 * el1 * el / dl1;
+          el = s_ * p;
+          if (lane == l) { ereg = el; dreg = c * p; }
+        } while (fabs(el) > eps * tst1 && iter < 80);
+      }
+      if (lane == l) { dreg += f; ereg = 0.0; }
+    }
+  }
+  // ---- rank the eigenvalues (descending, ties by index), write out
+  {
+    int rank = 0;
+    for (int j = 0; j < n; ++j) {
+      const double lj = pmd_readlane_f64(dreg, j);
+      rank += (lj > dreg) || (lj == dreg && j < lane);
+    }
+    if (live) order[rank] = lane;
+  }
+  __syncthreads();
+  {
+    // lane = output column c: eigenvector order[c], its eigenvalue and (mode 1) its scale; rows are walked in a loop so that
+    // the global stores are contiguous
+    const int src = live ? order[lane] : 0;
+    const double lam = __shfl(dreg, src);
+    const double lmax = pmd_readlane_f64(lam, 0);
+    double scl = 1.0;
+    if (mode == 1) scl = (lam > tol * lmax && lam > 0.0) ? 1.0 / sqrt(lam) : 0.0;
+    double* no = Nout + (long)blockIdx.x * 4096;
+    for (int r = 0; r < 64; ++r) no[r * 64 + lane] = (r < n && live) ? A[r * LD + src] * scl : 0.0;
+    lam_out[(long)blockIdx.x * 64 + lane] = live ? lam : 0.0;
+  }
+}
+
 int pmd_launch_small_eig(pmd_ctx* ctx, const double* G, int slices, int n, int mode, double tol, double* Nout,
                          double* lam_out, int n_tiles) {
   pmd_prof_scope prof__(ctx, "small_eig");
@@ -290,6 +494,19 @@ int pmd_launch_small_eig(pmd_ctx* ctx, const double* G, int slices, int n, int m
         ctx->scratch2_bytes = need;
       }
       return pmd_launch_wide_eig(ctx, G, slices, 64, n, mode, tol, Nout, lam_out, n_tiles, ctx->scratch2, ctx->scratch2_bytes);
+    }
+  }
+  {
+    // default: the one-wave QL kernel; PMD_SMALL_EIG=jacobi restores the parallel Jacobi kernel (A/B runs)
+    static int ql_mode = -1;
+    if (ql_mode < 0) { const char* e = getenv("PMD_SMALL_EIG"); ql_mode = (e && !strcmp(e, "jacobi")) ? 0 : 1; }
+    if (ql_mode) {
+      const size_t lds = ((size_t)n * (n + 1) + 2 * 64) * sizeof(double) + 64 * sizeof(int) + 64;
+      PMD_HIP(ctx, hipFuncSetAttribute((const void*)small_eig_ql_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(small_eig_ql_kernel, dim3(n_tiles), dim3(64), lds, ctx->stream, G, (long)slices * 4096, slices, n, mode, tol,
+                         Nout, lam_out);
+      PMD_LAUNCH_CHECK(ctx, "small_eig_ql_kernel");
+      return PMD_OK;
     }
   }
   const size_t bytes = (size_t)2 * 64 * EIG_LD * sizeof(double) + 64 * sizeof(double) + (64 + 2 + 64) * sizeof(int) + 64;
