@@ -137,6 +137,13 @@ def test_r_le_frames_at_scale_meets_the_north_star_vt_tolerance(gpu_ctx):
         assert m["u_data_err_stable"] < 1e-4 * m["u_data_max_abs"] and m["n_stable_cols_compared"] >= 32
         assert m["r_err_stable_signal"] < 2e-4 * m["r_max_abs"]
         assert m["probes"] < 5e-4, m["probes"]
+    # the reference's own arithmetic (oracle with single-precision LAPACK) against the arbiter, from the fixture: the HIP path
+    # is not farther from the exact result than that (measured: Vt 2.8e-5 against 4.4e-5)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "parity_rle.npz"), allow_pickle=False)
+    if "ref32s_vt_row_err" in g.files:
+        ma = out["f64"]
+        assert ma["vt_row_err"].max() <= 1.5 * g["ref32s_vt_row_err"].max() + 1e-5
+        assert ma["s_rel_signal"] <= 1.5 * g["ref32s_s_rel_signal"].max() + 1e-5
 
 
 def test_headline_regime_parity(gpu_ctx):
