@@ -160,6 +160,26 @@ class Context:
         self.handle = handle
         self._ws = None
         self._side = None
+        self._pin_free = {}     # page-locked staging buffers for host -> device table uploads, by size class
+        self._pin_used = []
+
+    def pinned(self, nbytes):
+        """A page-locked uint8 staging buffer of at least nbytes, owned by the context until release_pinned() (an asynchronous
+        copy out of pageable memory is a synchronous staged copy in disguise: 10+ ms for the 16 MB pixel lists of a
+        16 129-tile grid).  Buffers are kept between calls by power-of-two size class."""
+        import torch
+
+        size = 1 << max(12, int(nbytes - 1).bit_length())
+        pool = self._pin_free.setdefault(size, [])
+        buf = pool.pop() if pool else torch.empty(size, dtype=torch.uint8, pin_memory=True)
+        self._pin_used.append((size, buf))
+        return buf
+
+    def release_pinned(self):
+        """Return the staging buffers to the pool (call after a synchronisation: their transfers have completed)."""
+        for size, buf in self._pin_used:
+            self._pin_free.setdefault(size, []).append(buf)
+        self._pin_used = []
 
     def side(self):
         """A second context on its own HIP stream (``.stream``) for work that may overlap the main stream's

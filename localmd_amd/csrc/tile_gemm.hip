@@ -811,6 +811,80 @@ __global__ __launch_bounds__(256) void tile_rowmix_mfma_kernel(const float* __re
   }
 }
 
+// The same with 64 positions per step: a lane loads one float4 per K step (16 lanes x 16 B = 256 contiguous bytes per row,
+// four rows per instruction) and element e of it is the B operand of MFMA e, whose N index n then stands for position
+// x0 + 4 n + e; the four accumulators of a lane hold four consecutive positions of its output rows and leave as float4.
+// A quarter of the barriers and of the load / store instructions of the 16-position form: 18 -> 8 ms per step on the
+// 16 129-tile workload.  Needs 16-byte aligned rows (ld % 4 == 0) that can be read up to the next multiple of 4 behind len.
+__global__ __launch_bounds__(256) void tile_rowmix_mfma4_kernel(const float* __restrict__ In, long in_tile_stride,
+                                                                long ld_in, const double* __restrict__ N,
+                                                                long n_tile_stride, int n_in, int n_out,
+                                                                float* __restrict__ Out, long out_tile_stride,
+                                                                long ld_out, int len) {
+  const int tile = blockIdx.y;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (uniform, and known to be)
+  const int n16 = lane & 15, kq = lane >> 4;
+  const double* nsrc = N + (long)tile * n_tile_stride;
+  double a[16];
+#pragma unroll
+  for (int ks = 0; ks < 16; ++ks) {
+    const int cp = 4 * ks + kq, c = 16 * w + n16;
+    const double v = nsrc[cp * 64 + c];   // the 64 x 64 block always exists; entries outside n_in x n_out are masked
+    a[ks] = (cp < n_in && c < n_out) ? v : 0.0;
+  }
+  const float* in = In + (long)tile * in_tile_stride;
+  float* out = Out + (long)tile * out_tile_stride;
+  const int ksteps = (n_in + 3) / 4;
+  const int len4 = (len + 3) & ~3;
+  auto load = [&](int x0, f32x4 (&v)[16]) {
+    const int x = min(x0 + 4 * n16, len4 - 4);                       // clamped: a valid quad of the row
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(in + (long)min(4 * ks + kq, 63) * ld_in + x);   // unconditional, rows < 64 exist
+      const bool ok = 4 * ks + kq < n_in;                             // rows >= n_in may hold anything: 0 * NaN
+      v[ks] = ok ? t : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  f32x4 cur[16], nxt[16];
+  int x0 = blockIdx.x * 64;
+  if (x0 < len) load(x0, cur);
+  for (; x0 < len; x0 += gridDim.x * 64) {
+    const int xn = x0 + gridDim.x * 64;
+    if (xn < len) load(xn, nxt);
+    f64x4 acc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] = (f64x4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks)
+      if (ks < ksteps) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ks], (double)cur[ks][e], acc[e], 0, 0, 0);
+      }
+    __syncthreads();   // every wave holds this chunk's inputs in registers: outputs may overwrite them now
+    const int xs = x0 + 4 * n16;
+    if (xs < len) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = 16 * w + 4 * i + kq;
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (c < n_out) ? (float)acc[e][i] : 0.f;
+        float* dst = out + (long)c * ld_out + xs;
+        if (xs + 3 < len) *reinterpret_cast<f32x4*>(dst) = o;
+        else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (xs + e < len) dst[e] = o[e];
+        }
+      }
+    }
+    if (xn < len) {
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) cur[ks] = nxt[ks];
+    }
+  }
+}
+
 int pmd_launch_tile_rowmix(pmd_ctx* ctx, const float* In, long in_tile_stride, long ld_in, const double* N,
                            long n_tile_stride, int n_in, int n_out, float* Out, long out_tile_stride, long ld_out,
                            int len, int n_tiles) {
@@ -824,7 +898,20 @@ int pmd_launch_tile_rowmix(pmd_ctx* ctx, const float* In, long in_tile_stride, l
     const double* nn = N + (long)t0 * n_tile_stride;
     float* out = Out + (long)t0 * out_tile_stride;
     const char* rm = getenv("PMD_ROWMIX_MFMA");
-    if (n_out > 4 && !(rm && !strcmp(rm, "0"))) {
+    const bool quads = ld_in % 4 == 0 && ld_out % 4 == 0 && in_tile_stride % 4 == 0 && out_tile_stride % 4 == 0 && !((uintptr_t)in & 15) &&
+                       !((uintptr_t)out & 15) && ld_in >= ((len + 3) & ~3) && len >= 4 && !(rm && !strcmp(rm, "16"));
+    // (the 64-position form pays with 200 VGPRs - two workgroups per CU: it wins where tiles are plentiful and each one is
+    // small - 13.3 against 18.0 ms at 16 129 tiles x 1000 frames - and loses at 2601 tiles x 10^4 frames, 11.6 against 7.7)
+    if (n_out > 4 && !(rm && !strcmp(rm, "0")) && quads && (n_tiles >= 8192 || (rm && !strcmp(rm, "64")))) {
+      // workgroups per tile: each one first loads its slice of the 64 x 64 mixing matrix (32 KB per tile and workgroup),
+      // so no more of them than it takes to fill the chip (~8192 workgroups in all)
+      int bxm = (len + 63) / 64;
+      const int want = (8192 + tn - 1) / tn;
+      if (bxm > want) bxm = want;
+      if (bxm > 16) bxm = 16;
+      hipLaunchKernelGGL(tile_rowmix_mfma4_kernel, dim3(bxm, tn), dim3(256), 0, ctx->stream, in, in_tile_stride, ld_in, nn,
+                         n_tile_stride, n_in, n_out, out, out_tile_stride, ld_out, len);
+    } else if (n_out > 4 && !(rm && !strcmp(rm, "0"))) {
       int bxm = (len + 15) / 16;
       if (bxm > 16) bxm = 16;
       hipLaunchKernelGGL(tile_rowmix_mfma_kernel, dim3(bxm, tn), dim3(256), 0, ctx->stream, in, in_tile_stride, ld_in, nn,

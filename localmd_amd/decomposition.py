@@ -59,14 +59,25 @@ def _torch():
     return torch
 
 
-def _i32(ctx, arr):
+def _upload(ctx, arr, np_dtype):
+    """Host table -> device tensor.  Large tables go through a page-locked staging buffer of the context and an
+    asynchronous copy (released with ctx.release_pinned() after the next synchronisation)."""
     torch = _torch()
-    return torch.from_numpy(np.ascontiguousarray(arr, dtype=np.int32)).to(ctx.device)
+    a = np.ascontiguousarray(arr, dtype=np_dtype)
+    t = torch.from_numpy(a)
+    if a.nbytes < (1 << 18) or not hasattr(ctx, "pinned") or ctx.device.type != "cuda":
+        return t.to(ctx.device)
+    stage = ctx.pinned(a.nbytes)[:a.nbytes].view(t.dtype).view(t.shape)
+    stage.copy_(t)
+    return stage.to(ctx.device, non_blocking=True)
+
+
+def _i32(ctx, arr):
+    return _upload(ctx, arr, np.int32)
 
 
 def _f32(ctx, arr):
-    torch = _torch()
-    return torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float32)).to(ctx.device)
+    return _upload(ctx, arr, np.float32)
 
 
 def _round_up(x, m):
@@ -1339,6 +1350,12 @@ def localmd_decomposition(
         }
         return final_movie, diag
     finally:
+        if hasattr(ctx, "release_pinned"):
+            try:
+                ctx.sync()
+            except Exception:
+                pass
+            ctx.release_pinned()
         if own_ctx:
             ctx.release_workspace()
             ctx.close()

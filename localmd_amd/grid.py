@@ -83,18 +83,19 @@ def block_weight_matrix(block_sizes, dtype=np.float32) -> np.ndarray:
 
 def tile_pixel_lists(fov, block_sizes, dim_1_iters, dim_2_iters):
     """pix[tile][q]: C-order FOV pixel (i*d2 + j) of tile-local pixel q = il + b1*jl.
-    Tile order is k-outer / j-inner (decomposition.py:790-792).  Also returns origins[tile]."""
+    Tile order is k-outer / j-inner (decomposition.py:790-792).  Also returns origins[tile].
+    (One broadcast instead of a Python loop over the tiles: 52 ms of host time at 16 129 tiles, on the critical path.)"""
     d1, d2 = fov
     b1, b2 = block_sizes
-    il = np.arange(b1)[:, None]
-    jl = np.arange(b2)[None, :]
-    pix, origins = [], []
-    for k in dim_1_iters:
-        for j in dim_2_iters:
-            c = (k + il) * d2 + (j + jl)  # (b1, b2)
-            pix.append(c.reshape(-1, order="F"))
-            origins.append((k, j))
-    return np.asarray(pix, dtype=np.int32), np.asarray(origins, dtype=np.int32)
+    k = np.asarray(dim_1_iters, dtype=np.int64)
+    j = np.asarray(dim_2_iters, dtype=np.int64)
+    il = np.arange(b1, dtype=np.int64)
+    jl = np.arange(b2, dtype=np.int64)
+    # axes (tile row, tile column, jl, il): flattening the last two gives q = jl * b1 + il
+    c = (k[:, None, None, None] + il[None, None, None, :]) * d2 + (j[None, :, None, None] + jl[None, None, :, None])
+    pix = np.ascontiguousarray(c.reshape(len(k) * len(j), b1 * b2), dtype=np.int32)
+    origins = np.stack(np.meshgrid(k, j, indexing="ij"), axis=-1).reshape(-1, 2).astype(np.int32)
+    return pix, origins
 
 
 def pooling_maps(block_sizes, n):
@@ -182,11 +183,24 @@ def virtual_pairs(pairs, vt):
 
 
 def cumulative_weights(fov, block_sizes, origins, block_weights):
-    """Sum of the tile weights covering each pixel (decomposition.py:813-816), float64 (d1, d2)."""
-    cw = np.zeros(fov, dtype=np.float64)
+    """Sum of the tile weights covering each pixel (decomposition.py:813-816), float64 (d1, d2).  The origins form a product
+    grid, so the sum over the tile columns is the same strip for every tile row: n1 + n2 placements instead of n1 * n2
+    (the weights are small integers: the float64 sums are exact in any order)."""
     b1, b2 = block_sizes
-    for k, j in origins:
-        cw[k : k + b1, j : j + b2] += block_weights
+    origins = np.asarray(origins)
+    ks = np.unique(origins[:, 0])
+    js = np.unique(origins[:, 1])
+    if len(ks) * len(js) != len(origins):
+        cw = np.zeros(fov, dtype=np.float64)
+        for k, j in origins:
+            cw[k : k + b1, j : j + b2] += block_weights
+        return cw
+    strip = np.zeros((b1, fov[1]), dtype=np.float64)
+    for j in js:
+        strip[:, j : j + b2] += block_weights
+    cw = np.zeros(fov, dtype=np.float64)
+    for k in ks:
+        cw[k : k + b1, :] += strip
     return cw
 
 
