@@ -143,6 +143,11 @@ int pmd_weight_tiles(pmd_ctx* ctx, const float* Ut, int dpad, const int* tile_pi
  * the sparse product of pmd_loader.py:411).  A[tile][64][dpad]; Out[tile][64][ldo]. */
 int pmd_tiles_project(pmd_ctx* ctx, const float* x, long ldx, int T, const int* tile_pix, int n_tiles, int d,
                       const float* A, int dpad, float* Out, long ldo, int slices);
+/* The same when rows >= ranks[tile] of A are zero (the weighted, rank-masked bases of the movie projection): a tile that kept
+ * <= 32 components runs half the MFMA work, and rows >= 32 of its Out block are then NOT written (pmd_compact_rows reads
+ * rows < rank only). */
+int pmd_tiles_project_ranked(pmd_ctx* ctx, const float* x, long ldx, int T, const int* tile_pix, int n_tiles, int d,
+                             const float* A, int dpad, float* Out, long ldo, int slices, const int* ranks);
 /* Z[col_off[tile] + c][t] = Out[tile][c][t], c < ranks[tile] */
 int pmd_compact_rows(pmd_ctx* ctx, const float* Out, long ldo, const int* col_off, const int* ranks, int T, float* Z,
                      long ldz, int n_tiles);
@@ -244,6 +249,13 @@ int pmd_csr_fill(pmd_ctx* ctx, int d1, int d2, int order_f, int b1, const int* c
  * :1006; pmd_loader.py:412) */
 int pmd_gemm(pmd_ctx* ctx, int transA, int transB, int m, int n, int k, float alpha, const float* A, long lda,
              const float* B, long ldb, float beta, float* C, long ldc);
+/* 1 when pmd_gemm runs a product of this size as three fp16-piece products on the fp16 matrix cores (csrc/gemm_f16x2.hip:
+ * fp32 operands and result, error below the sgemm path's; PMD_GEMM_SPLIT=0 switches it off).  Those products accumulate
+ * into C, so C should then live in HBM (a host-mapped C takes the sgemm path). */
+int pmd_gemm_split_active(pmd_ctx* ctx, int m, int n, int k);
+/* Frees the library-owned device scratch of the large products (fp16 pieces, split-K partial sums) when it is larger than
+ * keep_bytes; it is re-created on demand.  The host driver calls it at the end of every decomposition. */
+int pmd_scratch_trim(pmd_ctx* ctx, size_t keep_bytes);
 
 /* A18: expansion back into pixels (pmdarray.py:132-171, PMDArray.__getitem__: spatial.dot(temporal), times the
  * noise image, plus the mean image, frames first).  pmd_csr_rows_spmm: out[p][f] = sum over the nonzeros i of CSR

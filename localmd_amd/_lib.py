@@ -59,6 +59,7 @@ SIGNATURES = {
     "pmd_tiles_truncate": (c_i, [c_p, c_p, c_i, c_p, c_i, c_i]),
     "pmd_weight_tiles": (c_i, [c_p, c_p, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_i]),
     "pmd_tiles_project": (c_i, [c_p, c_p, c_l, c_i, c_p, c_i, c_i, c_p, c_i, c_p, c_l, c_i]),
+    "pmd_tiles_project_ranked": (c_i, [c_p, c_p, c_l, c_i, c_p, c_i, c_i, c_p, c_i, c_p, c_l, c_i, c_p]),
     "pmd_compact_rows": (c_i, [c_p, c_p, c_l, c_p, c_p, c_i, c_p, c_l, c_i]),
     "pmd_gram_u": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_i, c_p, c_l, c_i, c_p, c_l]),
     "pmd_orthogonalize_workspace_bytes": (c_sz, [c_i, c_i, c_i]),
@@ -90,6 +91,8 @@ SIGNATURES = {
     "pmd_csr_count": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_i, c_p]),
     "pmd_csr_fill": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_i, c_i,
                            c_p, c_p, c_p, c_p, c_i]),
+    "pmd_scratch_trim": (c_i, [c_p, C.c_size_t]),
+    "pmd_gemm_split_active": (c_i, [c_p, c_i, c_i, c_i]),
     "pmd_gemm": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_l, c_p, c_l, c_f, c_p, c_l]),
     "pmdk_tile_atx": (c_i, [c_p, c_p, c_l, c_p, c_i, c_l, c_i, c_p, c_l, c_i, c_p, c_l, c_l, c_i, c_i, c_i]),
     "pmdk_tile_xbt": (c_i, [c_p, c_p, c_l, c_p, c_i, c_l, c_i, c_p, c_l, c_l, c_p, c_l, c_l, c_i, c_i, c_i, c_i]),

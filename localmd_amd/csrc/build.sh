@@ -5,7 +5,7 @@
 set -e
 cd "$(dirname "$0")"
 OUT=../libpmd_hip.so
-SRCS="capi.hip rng.hip prep.hip tile_gemm.hip small_la.hip wide.hip pipeline.hip global.hip sytrd.hip sytrd2.hip expand.hip diag.hip comm.hip"
+SRCS="capi.hip rng.hip prep.hip tile_gemm.hip small_la.hip wide.hip pipeline.hip global.hip gemm_f16x2.hip sytrd.hip sytrd2.hip expand.hip diag.hip comm.hip"
 OBJS=""
 PIDS=()
 NAMES=()
@@ -31,5 +31,5 @@ if [ -n "$FAILED" ]; then
   echo "build.sh: compile failed for:$FAILED" >&2
   exit 1
 fi
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o $OUT -L/opt/rocm/lib -lrocblas -lrocsolver -ldl -Wl,-rpath,/opt/rocm/lib
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o $OUT -L/opt/rocm/lib -lrocblas -lrocsolver -lhipblaslt -ldl -Wl,-rpath,/opt/rocm/lib
 echo "built $(realpath $OUT)"

@@ -23,15 +23,19 @@ int pmd_ctx_create(int device, void* hip_stream, pmd_ctx** out) {
   ctx->scratch_bytes = 0;
   ctx->scratch2 = nullptr;
   ctx->scratch2_bytes = 0;
+  ctx->atx_ranks = nullptr;
   ctx->split_ws = nullptr;
   ctx->split_ws_bytes = 0;
   {
-    // PMD_GEMM_SPLIT=3|6 (opt-in, default off): large fp32 products from bf16 pieces, see pmd_gemm_rm
+    // PMD_GEMM_SPLIT=0: every product through rocBLAS sgemm; default: products of >= PMD_GEMM_SPLIT_MIN_GFLOP (100) GFLOP with no
+    // dimension below PMD_GEMM_SPLIT_MIN_DIM (256) run as three fp16-piece products on the fp16 matrix cores (gemm_f16x2.hip)
     const char* gs = getenv("PMD_GEMM_SPLIT");
-    const int v = gs ? atoi(gs) : 0;
-    ctx->gemm_split = (v == 3 || v == 6) ? v : 0;
+    ctx->gemm_split = (gs && !strcmp(gs, "0")) ? 0 : 1;
     const char* gm = getenv("PMD_GEMM_SPLIT_MIN_GFLOP");
-    ctx->gemm_split_min_flop = (gm ? atof(gm) : 500.0) * 1e9;
+    ctx->gemm_split_min_flop = (gm ? atof(gm) : 100.0) * 1e9;
+    const char* gd = getenv("PMD_GEMM_SPLIT_MIN_DIM");
+    ctx->gemm_split_min_dim = gd ? atoi(gd) : 256;
+    ctx->f16x2 = nullptr;
   }
   ctx->blas = nullptr;
   ctx->err[0] = 0;
@@ -57,6 +61,7 @@ int pmd_ctx_destroy(pmd_ctx* ctx) {
   if (ctx->scratch) hipFree(ctx->scratch);
   if (ctx->scratch2) hipFree(ctx->scratch2);
   if (ctx->split_ws) hipFree(ctx->split_ws);
+  pmd_f16x2_destroy(ctx);
   if (ctx->blas) rocblas_destroy_handle(ctx->blas);
   delete ctx;
   return PMD_OK;
@@ -267,6 +272,17 @@ int pmd_tiles_project(pmd_ctx* ctx, const float* x, long ldx, int T, const int* 
   return rc;
 }
 
+int pmd_tiles_project_ranked(pmd_ctx* ctx, const float* x, long ldx, int T, const int* tile_pix, int n_tiles, int d,
+                             const float* A, int dpad, float* Out, long ldo, int slices, const int* ranks) {
+  CTX_CHECK(ctx);
+  ctx->atx_label = "tile_atx_proj";
+  ctx->atx_ranks = ranks;
+  const int rc = pmd_launch_tile_atx(ctx, x, ldx, tile_pix, d, 0, d, A, 64L * dpad, dpad, Out, 64L * ldo, ldo, n_tiles, T, slices);
+  ctx->atx_ranks = nullptr;
+  ctx->atx_label = nullptr;
+  return rc;
+}
+
 int pmd_compact_rows(pmd_ctx* ctx, const float* Out, long ldo, const int* col_off, const int* ranks, int T, float* Z,
                      long ldz, int n_tiles) {
   CTX_CHECK(ctx);
@@ -293,6 +309,16 @@ int pmd_projected_svd(pmd_ctx* ctx, const float* P, int rows_p, long ldp, const 
                       float* R_out, long ldr, float* s_out, float* Vt_out, long ldvt, void* ws, size_t ws_bytes) {
   CTX_CHECK(ctx);
   return pmd_projected_svd_impl(ctx, P, rows_p, ldp, V, n1, n2, ldv, R_out, ldr, s_out, Vt_out, ldvt, ws, ws_bytes);
+}
+
+int pmd_scratch_trim(pmd_ctx* ctx, size_t keep_bytes) {
+  CTX_CHECK(ctx);
+  return pmd_split_scratch_trim(ctx, keep_bytes);
+}
+
+int pmd_gemm_split_active(pmd_ctx* ctx, int m, int n, int k) {
+  if (!ctx) return 0;
+  return pmd_f16x2_wanted(ctx, m, n, k) ? 1 : 0;
 }
 
 int pmd_gemm(pmd_ctx* ctx, int transA, int transB, int m, int n, int k, float alpha, const float* A, long lda,

@@ -22,74 +22,6 @@
   } while (0)
 
 // row-major C(m x n) = alpha * op(A) * op(B) + beta * C
-// ---------------------------------------------------------------- split products (opt-in) --
-// PMD_GEMM_SPLIT=3|6: an fp32 product as a sum of bf16-piece products on the bf16 MFMA path, fp32 accumulation.
-// x = x1 + x2 (+ x3) with bf16 pieces (8 mantissa bits each).  "3": a1 b1 + a1 b2 + a2 b1 (drops terms of relative
-// size 2^-16 with random signs); "6": adds a1 b3 + a2 b2 + a3 b1 (drops 2^-24: below fp32 rounding).  Measured on the
-// shapes of the global stage (scripts/gemm_split_probe.hip, error against fp64 on sampled entries, relative rms):
-// sgemm 79 ms / 3.6e-6, "3" 32 ms / 4.0e-6, "6" 64 ms / 1.4e-6.  Default off: the bench line is plain sgemm.
-__global__ void split_bf16_kernel(const float* __restrict__ src, long ld, long rows, long cols, rocblas_bfloat16* __restrict__ p1,
-                                  rocblas_bfloat16* __restrict__ p2, rocblas_bfloat16* __restrict__ p3) {
-  const long total = rows * cols;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long r = i / cols, c = i - r * cols;
-    const float x = src[r * ld + c];
-    const unsigned u1 = (__float_as_uint(x) + 0x7fffu + ((__float_as_uint(x) >> 16) & 1u)) & 0xffff0000u;  // round to nearest even
-    const float f1 = __uint_as_float(u1);
-    const float r1 = x - f1;
-    const unsigned u2 = (__float_as_uint(r1) + 0x7fffu + ((__float_as_uint(r1) >> 16) & 1u)) & 0xffff0000u;
-    const float f2 = __uint_as_float(u2);
-    p1[i].data = (uint16_t)(u1 >> 16);
-    p2[i].data = (uint16_t)(u2 >> 16);
-    if (p3) {
-      const float r2 = r1 - f2;
-      const unsigned u3 = (__float_as_uint(r2) + 0x7fffu + ((__float_as_uint(r2) >> 16) & 1u)) & 0xffff0000u;
-      p3[i].data = (uint16_t)(u3 >> 16);
-    }
-  }
-}
-
-static int gemm_rm_split(pmd_ctx* ctx, int transA, int transB, int m, int n, int k, float alpha, const float* A, long lda,
-                         const float* B, long ldb, float beta, float* C, long ldc) {
-  pmd_prof_scope prof__(ctx, "gemm_split_bf16");
-  const int np = (ctx->gemm_split == 6) ? 3 : 2;
-  const long a_rows = transA ? k : m, a_cols = transA ? m : k, b_rows = transB ? n : k, b_cols = transB ? k : n;
-  const size_t na = (size_t)a_rows * a_cols, nb = (size_t)b_rows * b_cols;
-  const size_t need = (na + nb) * np * sizeof(rocblas_bfloat16) + 4096;
-  if (ctx->split_ws_bytes < need) {
-    PMD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->split_ws) (void)hipFree(ctx->split_ws);
-    ctx->split_ws = nullptr;
-    ctx->split_ws_bytes = 0;
-    PMD_HIP(ctx, hipMalloc(&ctx->split_ws, need));
-    ctx->split_ws_bytes = need;
-  }
-  rocblas_bfloat16* ap[3] = {nullptr, nullptr, nullptr};
-  rocblas_bfloat16* bp[3] = {nullptr, nullptr, nullptr};
-  rocblas_bfloat16* w = (rocblas_bfloat16*)ctx->split_ws;
-  for (int i = 0; i < np; ++i) { ap[i] = w; w += na; }
-  for (int i = 0; i < np; ++i) { bp[i] = w; w += nb; }
-  hipLaunchKernelGGL(split_bf16_kernel, dim3(8192), dim3(256), 0, ctx->stream, A, lda, a_rows, a_cols, ap[0], ap[1], ap[2]);
-  hipLaunchKernelGGL(split_bf16_kernel, dim3(8192), dim3(256), 0, ctx->stream, B, ldb, b_rows, b_cols, bp[0], bp[1], bp[2]);
-  PMD_LAUNCH_CHECK(ctx, "split_bf16_kernel");
-  // smallest terms first; the pieces are compact row-major arrays (leading dimension = their column count)
-  const int term3[3][2] = {{1, 0}, {0, 1}, {0, 0}};
-  const int term6[6][2] = {{2, 0}, {1, 1}, {0, 2}, {1, 0}, {0, 1}, {0, 0}};
-  const int nt = (np == 3) ? 6 : 3;
-  const float one = 1.f;
-  for (int t = 0; t < nt; ++t) {
-    const int ia = (np == 3) ? term6[t][0] : term3[t][0], ib = (np == 3) ? term6[t][1] : term3[t][1];
-    const float* bt = (t == 0) ? &beta : &one;
-    PMD_BLAS(ctx, rocblas_gemm_ex(ctx->blas, transB ? rocblas_operation_transpose : rocblas_operation_none,
-                                  transA ? rocblas_operation_transpose : rocblas_operation_none, n, m, k, &alpha, bp[ib],
-                                  rocblas_datatype_bf16_r, (rocblas_int)b_cols, ap[ia], rocblas_datatype_bf16_r,
-                                  (rocblas_int)a_cols, bt, C, rocblas_datatype_f32_r, (rocblas_int)ldc, C,
-                                  rocblas_datatype_f32_r, (rocblas_int)ldc, rocblas_datatype_f32_r,
-                                  rocblas_gemm_algo_standard, 0, 0));
-  }
-  return PMD_OK;
-}
-
 // ---------------------------------------------------------------- long inner dimension ------
 // A product with few output tiles and a very long inner dimension (M^T G M and M^T Z when R = 3e5 tile components meet
 // 1e3 frames: 1000 x 1000 outputs, k = 3e5) leaves most CUs idle in rocBLAS' sgemm (measured 20 TFLOP/s on the many-tile
@@ -131,15 +63,10 @@ static int gemm_rm_splitk(pmd_ctx* ctx, int transA, int transB, int m, int n, in
   const int slices = full + (rem ? 1 : 0);
   const long mn = (long)m * n;
   const size_t need = (size_t)slices * mn * sizeof(float) + 4096;
-  if (ctx->split_ws_bytes < need) {
-    PMD_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (ctx->split_ws) (void)hipFree(ctx->split_ws);
-    ctx->split_ws = nullptr;
-    ctx->split_ws_bytes = 0;
-    PMD_HIP(ctx, hipMalloc(&ctx->split_ws, need));
-    ctx->split_ws_bytes = need;
-  }
-  float* part = (float*)ctx->split_ws;
+  void* scratch = nullptr;
+  RUN(pmd_split_scratch(ctx, need, &scratch));
+  if (!scratch) return pmd_fail(ctx, PMD_ERR_HIP, "gemm_rm_splitk", "out of device memory for the partial sums");
+  float* part = (float*)scratch;
   const float zero = 0.f;
   const rocblas_operation opA = transA ? rocblas_operation_transpose : rocblas_operation_none;
   const rocblas_operation opB = transB ? rocblas_operation_transpose : rocblas_operation_none;
@@ -159,8 +86,13 @@ static int gemm_rm_splitk(pmd_ctx* ctx, int transA, int transB, int m, int n, in
 int pmd_gemm_rm(pmd_ctx* ctx, int transA, int transB, int m, int n, int k, float alpha, const float* A, long lda,
                 const float* B, long ldb, float beta, float* C, long ldc) {
   if (m <= 0 || n <= 0) return PMD_OK;
-  if (ctx->gemm_split && k > 0 && 2.0 * m * (double)n * k >= ctx->gemm_split_min_flop)
-    return gemm_rm_split(ctx, transA, transB, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc);
+  if (k > 0 && pmd_f16x2_wanted(ctx, m, n, k) && !pmd_is_host_pointer(C)) {
+    // large products: three fp16-piece products on the fp16 matrix cores, error below the fp32 path's (gemm_f16x2.hip);
+    // done = 0 (Inf / NaN / all-zero operands, no kernel for the shape): C is untouched and the fp32 path below runs
+    int done = 0;
+    RUN(pmd_gemm_f16x2(ctx, transA, transB, m, n, k, alpha, A, lda, B, ldb, beta, C, ldc, &done));
+    if (done) return PMD_OK;
+  }
   {
     // fewer than one 128 x 128 output tile per CU and an inner dimension that leaves >= 4096 per slice
     static int mode = -1;   // PMD_GEMM_SPLITK=0 switches the path off (A/B runs)
@@ -605,7 +537,8 @@ static int psvd_gram_rows(pmd_ctx* ctx, const float* V, int n1, int n2, long ldv
 int pmd_psvd_vp_gram_impl(pmd_ctx* ctx, const float* Et, int rp, int m, long lde, const float* W1, int nc, long ldw, int et_lower,
                           float* Vp, long ldv, float* C, long ldc) {
   if (nc > 0) {
-    const bool tri = et_lower && rp == m;
+    // (a triangular product does half the flops in fp32; the full product from fp16 pieces is faster still where it applies)
+    const bool tri = et_lower && rp == m && !pmd_f16x2_wanted(ctx, rp, nc, m);
     const float one = 1.f;
     if (tri) {
       pmd_prof_scope prof__(ctx, "rocblas_strmm");
@@ -1199,7 +1132,10 @@ int pmd_projected_svd_factored_impl(pmd_ctx* ctx, const float* M, int Rc, int m,
     RUN(pmd_gemm_rm(ctx, 0, 0, m, T, Rc, 1.f, Mt, Rc, Z, ldz, 0.f, W1, T));      // M^T Z
   }
   // (W1_in: the caller has formed M^T Z already, e.g. as an all-reduced sum of per-rank row-range partials)
-  const bool tri = et_lower && rp == m;  // Cholesky route: Et is lower triangular, strmm does half the work
+  // Cholesky route: Et is lower triangular (zeros above the diagonal), strmm does half the work in fp32; where the full
+  // product runs from fp16 pieces (gemm_f16x2.hip) that is faster still (6 against 10 ms at order 10^4)
+  const bool tri_any = et_lower && rp == m;
+  const bool tri = tri_any && !pmd_f16x2_wanted(ctx, rp, T, m);
   const float one = 1.f;
   if (tri) {
     // row-major Vp = Et W1  <=>  column-major Vp^T = W1^T Et^T with Et^T upper on the right
@@ -1214,7 +1150,7 @@ int pmd_projected_svd_factored_impl(pmd_ctx* ctx, const float* M, int Rc, int m,
   float* Wmat = W1;  // rp x rp  (rp <= m, T)
   RUN(pmd_projected_svd_impl(ctx, nullptr, 0, 0, Vp, rp, T, ldv, Wmat, rp, s_out, Vt_out, ldvt, sub, sub_bytes));
   // R = M (Et^T W)
-  if (tri) {
+  if (tri_any && !pmd_f16x2_wanted(ctx, m, rp, rp)) {
     // row-major X1 = Et^T W  <=>  column-major X1^T = W^T (Et^T)^T
     pmd_prof_scope prof__(ctx, "rocblas_strmm");
     PMD_BLAS(ctx, rocblas_strmm(ctx->blas, rocblas_side_right, rocblas_fill_upper, rocblas_operation_transpose,
@@ -1372,9 +1308,48 @@ int pmd_gram_mtgm_impl(pmd_ctx* ctx, const float* M, int rows, int m, long ldm, 
   const char* cbenv = getenv("PMD_C_BLOCKS");
   const int nblk = cbenv ? std::max(1, atoi(cbenv)) : 5;  // 2/3/4/5/6/8/12/16 blocks at m = 10^4: 70/64/57/52/59/58/60/67 ms
   const int bs = std::max(256, ((m + nblk - 1) / nblk + 255) / 256 * 256);
+  // fp16-piece products (gemm_f16x2.hip): both operands are split ONCE, the row blocks are views of the pieces
+  bool pieces = false;
+  pmd_f16x2_op ma, gb;
+  // This product stays on the fp32 path by default (PMD_F16X2_MTGM=1 opts in).  C is singular by construction on the
+  // R > frames route (its last pivot is the null direction, 3e-12 of the mean diagonal on the headline fixture) and the
+  // Cholesky step needs every other pivot positive: fp32 products are exact before accumulation, two fp16 pieces carry
+  // 22-23 bits, and with them the factorisation of that fixture fails (the route then falls back to the eigenvectors:
+  // s 5.5e-4 / Vt 3.4e-3 against the arbiter instead of 1.1e-4 / 1.5e-3).  Every other large product is insensitive:
+  // the same fixture gives the same figures to three digits with or without the pieces (scripts/debug_headline.py).
+  static int mtgm_pieces = -1;
+  if (mtgm_pieces < 0) { const char* e = getenv("PMD_F16X2_MTGM"); mtgm_pieces = (e && !strcmp(e, "1")) ? 1 : 0; }
+  if (mtgm_pieces && pmd_f16x2_wanted(ctx, std::min(bs, m), m, rows)) {
+    const size_t na = pmd_f16x2_bytes(m, rows), nb = pmd_f16x2_bytes(rows, m);
+    void* w = nullptr;
+    RUN(pmd_split_scratch(ctx, na + nb, &w));
+    const float* X[2] = {Mt, GM};
+    if (w) {
+    const int xr[2] = {m, rows}, xc[2] = {rows, m};
+    const long xl[2] = {rows, ldgm};
+    void* buf[2] = {w, (char*)w + na};
+    pmd_f16x2_op ops[2];
+    int usable = 0;
+    RUN(pmd_f16x2_split(ctx, 2, X, xr, xc, xl, buf, ops, &usable));
+    if (usable) { pieces = true; ma = ops[0]; gb = ops[1]; }
+    }
+  }
   for (int i0 = 0; i0 < m; i0 += bs) {
     const int nr = std::min(bs, m - i0);
-    RUN(pmd_gemm_rm(ctx, 0, 0, nr, i0 + nr, rows, 1.f, Mt + (long)i0 * rows, rows, GM, ldgm, 0.f, C + (long)i0 * ldc, ldc));
+    if (pieces) {
+      pmd_f16x2_op a = ma;
+      a.h1 += (long)i0 * ma.ld;
+      a.h2 += (long)i0 * ma.ld;
+      int done = 0;
+      RUN(pmd_f16x2_matmul(ctx, 0, 0, nr, i0 + nr, rows, 1.f, a, gb, 0.f, C + (long)i0 * ldc, ldc, &done));
+      if (done) continue;
+      pieces = false;   // (the product below may reuse the scratch that held the pieces)
+    }
+    const int keep = ctx->gemm_split;
+    if (!mtgm_pieces) ctx->gemm_split = 0;
+    const int rc = pmd_gemm_rm(ctx, 0, 0, nr, i0 + nr, rows, 1.f, Mt + (long)i0 * rows, rows, GM, ldgm, 0.f, C + (long)i0 * ldc, ldc);
+    ctx->gemm_split = keep;
+    RUN(rc);
   }
   return PMD_OK;
 }

@@ -36,13 +36,16 @@ struct pmd_ctx {
   float* tables;  // device: Hann window + FFT twiddles, see prep.hip
   char err[512];
   const char* atx_label;             // profiling name of the next tile_atx launches (NULL: "tile_atx")
+  const int* atx_ranks;              // per-tile ranks of the next tile_atx launches (projection: rows >= rank of A are zero), or NULL
   void* scratch;                     // library-owned device scratch of the eigensolver (sytrd.hip)
   size_t scratch_bytes;
   void* scratch2;                    // library-owned device scratch of the fp64 eigenvector refinement (sytrd.hip)
   size_t scratch2_bytes;
-  int gemm_split;                    // 0: rocBLAS sgemm; 3 / 6: large products as sums of bf16-piece products (opt-in)
+  int gemm_split;                    // 1 (default): large fp32 products as three fp16-piece products (gemm_f16x2.hip); 0: rocBLAS sgemm only
   double gemm_split_min_flop;        // ... for products with at least this many flops
-  void* split_ws;                    // library-owned device scratch of the split products (bf16 pieces)
+  int gemm_split_min_dim;            // ... and no dimension below this
+  void* f16x2;                       // state of gemm_f16x2.hip (hipBLASLt handle, plans), created on first use
+  void* split_ws;                    // library-owned device scratch of the split products (fp16 pieces, split-K partial sums)
   size_t split_ws_bytes;
   void* comm;                        // RCCL communicator (pmd_comm_init), NULL without one
   int comm_rank, comm_world;

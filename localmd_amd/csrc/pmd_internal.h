@@ -113,6 +113,25 @@ int pmd_background_rsvd_impl(pmd_ctx* ctx, const float* xs, long D, int n, long 
 int pmd_gemm_rm(pmd_ctx* ctx, int transA, int transB, int m, int n, int k, float alpha, const float* A, long lda,
                 const float* B, long ldb, float beta, float* C, long ldc);
 int pmd_gemm_k_chunk(int k);
+// gemm_f16x2.hip: fp32 products from two fp16 pieces per operand (X 2^-e = h1 + 2^-11 h2)
+struct pmd_f16x2_op {
+  const _Float16* h1;
+  const _Float16* h2;
+  long ld;
+  int e;
+};
+bool pmd_f16x2_wanted(const pmd_ctx* ctx, int m, int n, int k);
+long pmd_f16x2_ld(int cols);
+size_t pmd_f16x2_bytes(int rows, int cols);
+int pmd_f16x2_split(pmd_ctx* ctx, int count, const float* const* X, const int* rows, const int* cols, const long* ld, void* const* buf,
+                    pmd_f16x2_op* ops, int* usable);
+int pmd_f16x2_matmul(pmd_ctx* ctx, int tA, int tB, int m, int n, int k, float alpha, const pmd_f16x2_op& a, const pmd_f16x2_op& b, float beta,
+                     float* C, long ldc, int* done);
+int pmd_gemm_f16x2(pmd_ctx* ctx, int transA, int transB, int m, int n, int k, float alpha, const float* A, long lda, const float* B, long ldb,
+                   float beta, float* C, long ldc, int* done);
+int pmd_split_scratch(pmd_ctx* ctx, size_t need, void** out);
+int pmd_split_scratch_trim(pmd_ctx* ctx, size_t keep_bytes);
+void pmd_f16x2_destroy(pmd_ctx* ctx);
 bool pmd_is_host_pointer(const void* p);
 int pmd_syevd(pmd_ctx* ctx, int n, float* A, long lda, float* w, float* work, int* info);
 size_t pmd_sy2sb_workspace_bytes_impl(int n);

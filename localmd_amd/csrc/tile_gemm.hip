@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void tile_atx_dma_kernel(const float* __restri
                                                            long row0_stride, int d, const float* __restrict__ A,
                                                            long a_tile_stride, int a_ld, float* __restrict__ Out,
                                                            long out_tile_stride, long ldo, int n_chunks_total,
-                                                           int chunks_per_slice) {
+                                                           int chunks_per_slice, const int* __restrict__ tile_ranks) {
   constexpr int DPAD = 16 * KJW;
   constexpr int BUF = DPAD * 32;           // floats per ring buffer
   constexpr int NINS = DPAD / 8;           // 1-KiB pieces per chunk
@@ -231,9 +231,15 @@ __global__ __launch_bounds__(256) void tile_atx_dma_kernel(const float* __restri
   const int c_end = min(n_chunks_total, c_begin + chunks_per_slice);
   if (c_begin >= c_end) return;
 
+  // tile_ranks (projection launches): a tile that kept <= 32 components has only two non-zero 16-row tiles of A.  Its four
+  // waves then take (row tile, frame tile) = (wid & 1, wid >> 1) - one frame tile each instead of two, half the MFMAs and
+  // LDS operand reads per wave - and rows >= 32 of the output are not written (the callers compact rows < rank only).
+  const bool half = tile_ranks != nullptr && __builtin_amdgcn_readfirstlane(tile_ranks[tile]) <= 32;
+  const int mrow = half ? (wid & 1) : wid;
+  const int nsel = wid >> 1;
   f32x4 areg[KJW];
   {
-    const float* ap = A + (long)tile * a_tile_stride + (long)(16 * wid + n16) * a_ld + 4 * kk;
+    const float* ap = A + (long)tile * a_tile_stride + (long)(16 * mrow + n16) * a_ld + 4 * kk;
 #pragma unroll
     for (int J = 0; J < KJW; ++J) areg[J] = *reinterpret_cast<const f32x4*>(ap + 16 * J);
   }
@@ -267,8 +273,52 @@ __global__ __launch_bounds__(256) void tile_atx_dma_kernel(const float* __restri
   const int f = 4 * (kk & 1);
   const int off0 = (4 * kk) * 32 + (((n16 >> 2) ^ f) << 2) + (n16 & 3);
   const int off1 = (4 * kk) * 32 + (((4 + (n16 >> 2)) ^ f) << 2) + (n16 & 3);
-  float* outp = Out + (long)tile * out_tile_stride + (long)(16 * wid + 4 * kk) * ldo + n16;
+  float* outp = Out + (long)tile * out_tile_stride + (long)(16 * mrow + 4 * kk) * ldo + n16;
   const bool full = wid + 4 * (NSLOT - 1) < NINS;  // this wave issues NSLOT (else NSLOT - 1) pieces per chunk
+  if (half) {
+    const int offn = nsel ? off1 : off0;
+    outp += 16 * nsel;
+    for (int c = c_begin; c < c_end; ++c) {
+      const int cur = (c - c_begin) % 3;
+      issue(c + 2, (c - c_begin + 2) % 3);
+      const float* xn = lds + cur * BUF + offn;
+      // one frame tile per wave; two accumulator chains (s even / odd) cover the MFMA latency
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      float b0[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) b0[s] = xn[s * 32];
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+      for (int J = 0; J < KJW; ++J) {
+        float n0[4];
+        if (J + 1 < KJW) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) n0[s] = xn[(16 * (J + 1) + s) * 32];
+        }
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[J][0], b0[0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[J][1], b0[1], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[J][2], b0[2], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[J][3], b0[3], acc1, 0, 0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        if (J + 1 < KJW) {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) b0[s] = n0[s];
+        }
+      }
+      {
+        float* o = outp + (long)c * 32;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[(long)i * ldo] = acc0[i] + acc1[i];
+      }
+      // chunk c + 1 must have landed: still allowed in flight are the pieces of chunk c + 2 and the 4 stores above
+      if (full) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MYINS + 4) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(MYINS - 1 + 4) : "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return;
+  }
   for (int c = c_begin; c < c_end; ++c) {
     const int cur = (c - c_begin) % 3;
     issue(c + 2, (c - c_begin + 2) % 3);
@@ -314,7 +364,7 @@ __global__ __launch_bounds__(256) void tile_atx_dma_kernel(const float* __restri
 template <int KJW>
 static int launch_atx_dma(pmd_ctx* ctx, const float* X, long ldx, const int* pix, int pix_stride, long row0_stride, int d,
                           const float* A, long a_tile_stride, int a_ld, float* Out, long out_tile_stride, long ldo,
-                          int n_tiles, int T, int slices) {
+                          int n_tiles, int T, int slices, const int* tile_ranks) {
   const size_t lds = (size_t)3 * 16 * KJW * 32 * sizeof(float);
   auto kern = tile_atx_dma_kernel<KJW>;
   PMD_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -324,7 +374,7 @@ static int launch_atx_dma(pmd_ctx* ctx, const float* X, long ldx, const int* pix
   const int cps = (n_chunks + slices - 1) / slices;
   const int ny = (n_chunks + cps - 1) / cps;
   hipLaunchKernelGGL(kern, dim3(n_tiles, ny, 1), dim3(256), lds, ctx->stream, X, ldx, pix, pix_stride, row0_stride, d, A,
-                     a_tile_stride, a_ld, Out, out_tile_stride, ldo, n_chunks, cps);
+                     a_tile_stride, a_ld, Out, out_tile_stride, ldo, n_chunks, cps, tile_ranks);
   PMD_LAUNCH_CHECK(ctx, "tile_atx_dma_kernel");
   return PMD_OK;
 }
@@ -379,7 +429,7 @@ int pmd_launch_tile_atx(pmd_ctx* ctx, const float* X, long ldx, const int* pix, 
     const bool dma_ok = !(dm && !strcmp(dm, "0")) && ldx >= 32L * ((T + 31) / 32 + 2) && (ldx % 4) == 0;
     if (v.kjw == 25 && v.ks == 1 && dma_ok)
       return launch_atx_dma<25>(ctx, X, ldx, pix, pix_stride, row0_stride, d, A, a_tile_stride, a_ld, Out, out_tile_stride,
-                                ldo, n_tiles, T, slices);
+                                ldo, n_tiles, T, slices, ctx->atx_ranks);
   }
   ATX_CASE(16, 1, 2)
   ATX_CASE(25, 1, 1)

@@ -927,8 +927,8 @@ def localmd_decomposition(
                 for b0, b1_ in batches:
                     nb_, g0 = b1_ - b0, t_lo + b0
                     proj = torch.empty((nb_, 64, ld_T), dtype=torch.float32, device=ctx.device)
-                    ctx.call("pmd_tiles_project", ptr(src), ld_T, T, ptr(pix_loc_dev[b0:]), nb_, d, ptr(uw_dev[g0:]), dpad,
-                             ptr(proj), ld_T, 2)
+                    ctx.call("pmd_tiles_project_ranked", ptr(src), ld_T, T, ptr(pix_loc_dev[b0:]), nb_, d, ptr(uw_dev[g0:]), dpad,
+                             ptr(proj), ld_T, 2, ptr(ranks_dev[g0:]))
                     ctx.call("pmd_compact_rows", ptr(proj), ld_T, ptr(col_off_dev[g0:]), ptr(ranks_dev[g0:]), T, ptr(z), T, nb_)
                     del proj
             elif n_loc > 0:
@@ -936,8 +936,8 @@ def localmd_decomposition(
                     proj = v_dev     # same shape; the fit-frame traces are already compacted into v_cropped
                 else:
                     proj = torch.empty((n_tiles, 64, ld_T), dtype=torch.float32, device=ctx.device)
-                ctx.call("pmd_tiles_project", ptr(src), ld_T, T, ptr(pix_loc_dev), n_loc, d, ptr(uw_dev[t_lo:]), dpad,
-                         ptr(proj[t_lo:]), ld_T, 2)
+                ctx.call("pmd_tiles_project_ranked", ptr(src), ld_T, T, ptr(pix_loc_dev), n_loc, d, ptr(uw_dev[t_lo:]), dpad,
+                         ptr(proj[t_lo:]), ld_T, 2, ptr(ranks_dev[t_lo:]))
                 ctx.call("pmd_compact_rows", ptr(proj[t_lo:]), ld_T, ptr(col_off_dev[t_lo:]), ptr(ranks_dev[t_lo:]), T, ptr(z), T,
                          n_loc)
             if xs_full is None and K > 0:
@@ -1162,8 +1162,9 @@ def localmd_decomposition(
             # device copy of R only where rows are exchanged between ranks; rank 0's own rows go straight to the host
             # Zero copy only for the large case it was measured on: for small outputs rocBLAS may pick split-K kernels
             # that read-modify-write C, which is ruinous across PCIe (58 ms instead of 1 ms at 5015 x 1999).
-            # (not with PMD_GEMM_SPLIT: its passes accumulate into C, which must then live in HBM)
-            split_gemm = os.environ.get("PMD_GEMM_SPLIT", "0") in ("3", "6")
+            # (not when the product runs as fp16-piece products, gemm_f16x2.hip: its three passes accumulate into C, which
+            # must then live in HBM; R is formed in row blocks there, each downloaded while the next is computed)
+            split_gemm = bool(lib.pmd_gemm_split_active(ctx.handle, min(Rc, 16384), nk, m_used))
             zero_copy = (not shard or dist.rank == 0) and m_used >= 8192 and Rc * nk * 4 >= 2 ** 30 and not split_gemm
             R_out = torch.empty((Rc, nko), dtype=torch.float32, device=ctx.device) if (shard or not zero_copy) else None
             s_out = torch.empty((nko,), dtype=torch.float32, device=ctx.device)
@@ -1270,10 +1271,19 @@ def localmd_decomposition(
                         r_host[r_lo:r_hi, nk:nko].copy_(p_null)
                     else:
                         R_out[r_lo:r_hi, nk:nko] = p_null
-                ctx.call("pmd_gemm", 0, 0, r_hi - r_lo, nk, m_used, 1.0, ptr(right[r_lo:]), m_cols, ptr(X1), rp, 0.0,
-                         ptr(dst), nko)
-                if root and not zero_copy:
-                    download(r_lo, r_hi)
+                if root and not zero_copy and split_gemm and (r_hi - r_lo) * nk * 4 >= 2 ** 30:
+                    n_blk = int(os.environ.get("PMD_R_BLOCKS", "4"))
+                    step_r = max(4096, -(-(r_hi - r_lo) // n_blk // 256) * 256)
+                    for b_lo in range(r_lo, r_hi, step_r):
+                        b_hi = min(r_hi, b_lo + step_r)
+                        ctx.call("pmd_gemm", 0, 0, b_hi - b_lo, nk, m_used, 1.0, ptr(right[b_lo:]), m_cols, ptr(X1), rp, 0.0,
+                                 ptr(R_out[b_lo:]), nko)
+                        download(b_lo, b_hi)
+                else:
+                    ctx.call("pmd_gemm", 0, 0, r_hi - r_lo, nk, m_used, 1.0, ptr(right[r_lo:]), m_cols, ptr(X1), rp, 0.0,
+                             ptr(dst), nko)
+                    if root and not zero_copy:
+                        download(r_lo, r_hi)
             if shard:
                 # the other ranks' row blocks of R travel to rank 0 and are downloaded as they arrive
                 ctx.sync()
@@ -1356,6 +1366,11 @@ def localmd_decomposition(
             except Exception:
                 pass
             ctx.release_pinned()
+            try:
+                # scratch of the large products: kept between calls up to 8 GiB, larger ones are returned to the device
+                ctx.call("pmd_scratch_trim", 8 << 30)
+            except Exception:
+                pass
         if own_ctx:
             ctx.release_workspace()
             ctx.close()

@@ -26,6 +26,6 @@ for rep in range(2):
                                                   thresholds=tuple(g["f32_thresholds"]), return_diagnostics=True, ctx=ctx)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
 m = PM.measure_fixture(pmd, diag, fx)
-print(sys.argv[1:], f"{dt:.3f} s; null {diag['null_direction']}", flush=True)
+print(sys.argv[1:], f"{dt:.3f} s; orthogonalizer {diag['orthogonalizer']}; null {diag['null_direction']}", flush=True)
 for ln in PM.fixture_summary("HIP vs arbiter", m)[1:3]:
     print("   ", ln, flush=True)

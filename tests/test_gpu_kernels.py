@@ -89,6 +89,37 @@ def test_tile_atx_consecutive_rows(gpu_ctx):
     _atx_case(gpu_ctx, 100, 250, n_tiles=7, rows=700, slices=1, use_pix=False)
 
 
+@pytest.mark.parametrize("d,T", [(400, 1000), (400, 77), (256, 333)])
+def test_tiles_project_ranked(gpu_ctx, d, T):
+    """pmd_tiles_project_ranked: tiles with rank <= 32 take the half-work route; rows < rank must equal the plain projection
+    and rows >= 32 of such a tile stay untouched."""
+    ctx, torch = gpu_ctx, _t()
+    lib = ctx.lib
+    rng = np.random.default_rng(5)
+    n_tiles, rows = 9, 1200
+    ld, dpad = lib.pmd_time_ld(T), lib.pmd_tile_dpad(d)
+    X = np.zeros((rows, ld), dtype=np.float32)
+    X[:, :T] = rng.standard_normal((rows, T)).astype(np.float32)
+    pix = np.stack([rng.choice(rows, size=d, replace=False) for _ in range(n_tiles)]).astype(np.int32)
+    ranks = np.array([0, 1, 16, 17, 31, 32, 33, 50, 64], dtype=np.int32)
+    A = np.zeros((n_tiles, 64, dpad), dtype=np.float32)
+    for t, r in enumerate(ranks):
+        A[t, :r, :d] = rng.standard_normal((r, d)).astype(np.float32)
+    Out = torch.full((n_tiles, 64, ld), np.nan, dtype=torch.float32, device=ctx.device)
+    Xd, Ad, pd, rd = dev(ctx, X), dev(ctx, A), dev(ctx, pix), dev(ctx, ranks)
+    ctx.call("pmd_tiles_project_ranked", P(Xd), ld, T, P(pd), n_tiles, d, P(Ad), dpad, P(Out), ld, 2, P(rd))
+    ctx.sync()
+    got = Out.cpu().numpy()[:, :, :T]
+    ref = np.einsum("ncq,nqt->nct", A[:, :, :d].astype(np.float64), X[pix][:, :, :T].astype(np.float64))
+    scale = np.abs(ref).max()
+    for t, r in enumerate(ranks):
+        top = 32 if r <= 32 else 64
+        assert np.abs(got[t, :top] - ref[t, :top]).max() / scale < 2e-6, (t, r)
+        if top == 32:
+            # untouched (the staged variant for 256 < d <= 400) or the plain product (every other variant)
+            assert np.isnan(got[t, 32:]).all() or np.abs(got[t, 32:] - ref[t, 32:]).max() / scale < 2e-6, (t, r)
+
+
 def _xbt_case(ctx, d, T, n_tiles, rows, slices, shared_b=False, seed=1):
     torch = _t()
     lib = ctx.lib
@@ -595,37 +626,75 @@ def test_sytrd_advance_forms_agree(gpu_ctx, monkeypatch):
     assert abs(d1.sum() - d0.sum()) < 1e-5 * abs(d0.sum())
 
 
-@pytest.mark.parametrize("mode", ["3", "6"])
-def test_gemm_split_option(mode, monkeypatch):
-    """PMD_GEMM_SPLIT (opt-in): row-major C = alpha op(A) op(B) + beta C from bf16 pieces with fp32 accumulation, all four
-    transpose combinations, leading dimensions larger than the rows; error against fp64 well below bf16 rounding."""
+@pytest.mark.parametrize("kind", ["normal", "positive", "decades", "tiny", "huge"])
+def test_gemm_fp16_pieces(kind, monkeypatch):
+    """Large products of pmd_gemm run as three fp16-piece products on the fp16 matrix cores (csrc/gemm_f16x2.hip); forced
+    here onto a small product: row-major C = alpha op(A) op(B) + beta C, all four transpose combinations, leading
+    dimensions larger than the rows, operands of every scale.  The error against fp64 must be at the level of an fp32
+    product (the sgemm path of the same library is measured next to it), padding columns of C untouched."""
     torch = _t()
     from localmd_amd._lib import Context
 
-    monkeypatch.setenv("PMD_GEMM_SPLIT", mode)
     monkeypatch.setenv("PMD_GEMM_SPLIT_MIN_GFLOP", "0")
-    ctx = Context(0)  # the option is read when a context is created
+    monkeypatch.setenv("PMD_GEMM_SPLIT_MIN_DIM", "1")
+    ctx = Context(0)  # the options are read when a context is created
+    monkeypatch.setenv("PMD_GEMM_SPLIT", "0")
+    ref_ctx = Context(0)
     try:
         rng = np.random.default_rng(3)
         m, n, k = 192, 160, 3000
+        assert ctx.lib.pmd_gemm_split_active(ctx.handle, m, n, k) == 1
+        assert ref_ctx.lib.pmd_gemm_split_active(ref_ctx.handle, m, n, k) == 0
         for ta, tb in ((0, 0), (1, 0), (0, 1), (1, 1)):
-            a = rng.standard_normal((k, m) if ta else (m, k)).astype(np.float32)
-            b = rng.standard_normal((n, k) if tb else (k, n)).astype(np.float32)
-            c0 = rng.standard_normal((m, n)).astype(np.float32)
+            a = rng.standard_normal((k, m) if ta else (m, k))
+            b = rng.standard_normal((n, k) if tb else (k, n))
+            if kind == "positive":
+                a, b = np.abs(a), np.abs(b)
+            elif kind == "decades":   # inner index spread over six decades in both operands, outer over three
+                wk = 10.0 ** (-6 * rng.random(k))
+                a = a * (wk[:, None] if ta else wk[None, :]) * 10.0 ** (-3 * rng.random((1, m) if ta else (m, 1)))
+                b = b * (wk[None, :] if tb else wk[:, None])
+            elif kind == "tiny":
+                a, b = a * 1e-20, b * 1e-12
+            elif kind == "huge":
+                a, b = a * 1e15, b * 1e12
+            a, b = a.astype(np.float32), b.astype(np.float32)
+            c0 = (rng.standard_normal((m, n)) * np.abs(a).max() * np.abs(b).max() * 50).astype(np.float32)
             lda, ldb, ldc = a.shape[1] + 4, b.shape[1] + 8, n + 4
             ab = np.zeros((a.shape[0], lda), np.float32); ab[:, :a.shape[1]] = a
             bb = np.zeros((b.shape[0], ldb), np.float32); bb[:, :b.shape[1]] = b
             cb = np.zeros((m, ldc), np.float32); cb[:, :n] = c0
-            ad, bd, cd = dev(ctx, ab), dev(ctx, bb), dev(ctx, cb)
-            ctx.call("pmd_gemm", ta, tb, m, n, k, 0.5, P(ad), lda, P(bd), ldb, -2.0, P(cd), ldc)
-            ctx.sync()
             ref = 0.5 * ((a.T if ta else a).astype(np.float64) @ (b.T if tb else b).astype(np.float64)) - 2.0 * c0
-            got = cd.cpu().numpy()[:, :n]
-            err = np.linalg.norm(got - ref) / np.linalg.norm(ref)
-            assert err < (2e-5 if mode == "3" else 2e-6), (ta, tb, err)
-            assert np.all(cd.cpu().numpy()[:, n:] == 0)
+            errs = []
+            for cx in (ctx, ref_ctx):
+                ad, bd, cd = dev(cx, ab), dev(cx, bb), dev(cx, cb)
+                cx.call("pmd_gemm", ta, tb, m, n, k, 0.5, P(ad), lda, P(bd), ldb, -2.0, P(cd), ldc)
+                cx.sync()
+                got = cd.cpu().numpy()
+                assert np.all(got[:, n:] == 0)
+                errs.append(np.linalg.norm(got[:, :n] - ref) / np.linalg.norm(ref))
+            assert errs[0] < 3e-7 and errs[0] < 2.0 * errs[1] + 1e-7, (kind, ta, tb, errs)
+        # operands the pieces cannot hold go to the fp32 path: NaN / Inf propagate, an all-zero operand gives beta C
+        a = rng.standard_normal((m, k)).astype(np.float32)
+        b = rng.standard_normal((k, n)).astype(np.float32)
+        c0 = rng.standard_normal((m, n)).astype(np.float32)
+        for poison, expect in ((np.nan, "nan"), (np.inf, "inf"), (0.0, "zero")):
+            a2 = a.copy()
+            if expect == "zero":
+                a2[:] = 0
+            else:
+                a2[7, 11] = poison
+            ad, bd, cd = dev(ctx, a2), dev(ctx, b), dev(ctx, c0)
+            ctx.call("pmd_gemm", 0, 0, m, n, k, 1.0, P(ad), k, P(bd), n, 3.0, P(cd), n)
+            ctx.sync()
+            got = cd.cpu().numpy()
+            if expect == "zero":
+                np.testing.assert_array_equal(got, 3.0 * c0)
+            else:
+                assert not np.isfinite(got[7]).any() and np.isfinite(np.delete(got, 7, axis=0)).all()
     finally:
         ctx.close()
+        ref_ctx.close()
 
 
 @pytest.mark.parametrize("ta,tb", [(0, 0), (1, 0), (0, 1), (1, 1)])
