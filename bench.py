@@ -167,12 +167,16 @@ def main():
             def slab(self, i_lo, i_hi):
                 t, self._t = self._t, None
                 if t is None:
-                    raise RuntimeError("one-shot source already consumed: --steps 1 --warmup 0 --no-host-input only")
+                    raise RuntimeError("one-shot source already consumed")
                 return t[:, i_lo:i_hi, :]
 
-        if args.steps != 1 or args.warmup != 0:
-            raise SystemExit("this workload runs one step only: --steps 1 --warmup 0")
-        movie = OneShotSource(make_movie_torch(cfg["T"], cfg["d1"], cfg["d2"], device, seed=0))
+        def fresh_movie():
+            # the movie is rebuilt (untimed) before every step: the step before consumed the only copy
+            return OneShotSource(make_movie_torch(cfg["T"], cfg["d1"], cfg["d2"], device, seed=0))
+
+        if args.no_host_input is False:
+            args.no_host_input = True
+        movie = None
     else:
         movie = make_movie_torch(cfg["T"], cfg["d1"], cfg["d2"], device, seed=0)
     ctx = Context(local_rank)
@@ -189,27 +193,42 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        one_step()
-    barrier()
     # The timed steps run WITHOUT the library's HIP-event profiling (round-2 verdict: measurement overhead does not
     # belong in the headline number); the per-kernel times and both roofline objects come from the one extra,
-    # untimed, instrumented step below.  Exception: a one-shot workload has only one step, which is then both.
+    # untimed, instrumented step below.
+    cold_ms = None
+    if cfg.get("one_shot"):
+        # one-shot workloads (the movie fills a third of the HBM and is consumed by the step): every step gets a freshly
+        # built movie, built outside the timed regions; each timed step is bracketed on its own and the times are summed
+        for w in range(args.warmup):
+            movie = fresh_movie()
+            barrier()
+            tc = time.perf_counter()
+            one_step()
+            barrier()
+            if w == 0:
+                cold_ms = 1e3 * (time.perf_counter() - tc)   # first call of the process: every allocation is new
+        elapsed = 0.0
+        for _ in range(args.steps):
+            movie = fresh_movie()
+            barrier()
+            t0 = time.perf_counter()
+            one_step()
+            barrier()
+            elapsed += time.perf_counter() - t0
+    else:
+        for _ in range(args.warmup):
+            one_step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            one_step()
+        barrier()
+        elapsed = time.perf_counter() - t0
     one_shot_diag = None
     prof = None
-    if cfg.get("one_shot"):
-        ctx.profile_enable(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        if cfg.get("one_shot"):
-            _, one_shot_diag = one_step(diag=True)   # the only run there is (its diagnostics cost a few syncs)
-        else:
-            one_step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if cfg.get("one_shot"):
-        prof = ctx.profile_summary()
-        ctx.profile_enable(False)
+    if cfg.get("one_shot") and movie is not None and getattr(movie, "_t", None) is None:
+        movie = None
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -218,6 +237,8 @@ def main():
     # one extra, untimed, instrumented run: per-phase breakdown, tile statistics, per-kernel HIP-event times
     diag = one_shot_diag
     if diag is None:
+        if cfg.get("one_shot"):
+            movie = fresh_movie()
         ctx.profile_enable(True)
         _, diag = one_step(diag=True)
         barrier()
@@ -342,9 +363,14 @@ def main():
         "phases_ms": {k: 1e3 * v for k, v in diag["timings"].items()},
         "hbm_peak_allocated_gb": torch.cuda.max_memory_allocated(device) / 2 ** 30,
         "kernel_ms_per_step": {k: v[0] for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
-        "kernel_ms_source": "HIP events on the launch stream during one untimed instrumented step" if not cfg.get("one_shot")
-                            else "HIP events on the launch stream during the (only) timed step",
+        "kernel_ms_source": "HIP events on the launch stream during one untimed instrumented step",
+        "arithmetic": "fp32 operands, results and accumulation; products of >= 100 GFLOP outside the tile stage run as three "
+                      "fp16-piece matrix-core products per product (two fp16 pieces per operand, power-of-two scaling, measured "
+                      "error below the sgemm path's: DESIGN 4a, tests/test_gpu_kernels.py::test_gemm_fp16_pieces); M^T G M, "
+                      "the Gram matrices and the tile stage are fp32 MFMA; PMD_GEMM_SPLIT=0 = sgemm everywhere",
     }
+    if cold_ms is not None:
+        out["cold_first_step_ms"] = cold_ms   # the first call of the process (every device / pinned allocation is new)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg, movie, seed)
     if rank == 0:
