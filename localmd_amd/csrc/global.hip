@@ -1176,8 +1176,14 @@ int pmd_projected_svd_factored_impl(pmd_ctx* ctx, const float* M, int Rc, int m,
 #define CHOL_NB 128
 // n_abs_last > 0: a negative pivot number n_abs_last (1-based, the LAST pivot of the whole matrix) is replaced by its
 // absolute value - the Cholesky-route form of the reference keeping a numerically null direction through |lambda|.
+// linv_out != NULL: the inverse of the factor, row-major lower triangle L^{-1} with leading dimension CHOL_NB (zeros above the
+// diagonal), is formed in the same launch (dynamic LDS: two CHOL_NB x CHOL_LS float arrays): the factor goes to LDS, thread c
+// solves L x = e_c by forward substitution (column c of the inverse, kept in LDS).  This replaces rocBLAS' strtri on the
+// block (five launches, 150 us in its diagonal kernel) in the latency-bound chain of the blocked factorisation.
+#define CHOL_LS (CHOL_NB + 1)
 __global__ __launch_bounds__(256) void potf2_block_kernel(float* __restrict__ A, long ld, int nb, int k0, int* __restrict__ info,
-                                                          int n_abs_last) {
+                                                          int n_abs_last, float* __restrict__ linv_out) {
+  extern __shared__ float chol_dyn[];
   __shared__ float s_col[2][CHOL_NB];
   const int tid = threadIdx.x;
   const int tr = tid >> 4, tc = tid & 15;
@@ -1251,6 +1257,114 @@ __global__ __launch_bounds__(256) void potf2_block_kernel(float* __restrict__ A,
       const int r = tr + 16 * i, c = tc + 16 * j;
       if (r < nb && c <= r) A[(long)r * ld + c] = a[i][j];
     }
+  if (!linv_out) return;
+  float* Ls = chol_dyn;
+  float* Xs = chol_dyn + CHOL_NB * CHOL_LS;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int r = tr + 16 * i, c = tc + 16 * j;
+      if (r < nb && c <= r) Ls[r * CHOL_LS + c] = a[i][j];
+    }
+  __syncthreads();
+  {
+    // two lanes per column (even / odd k), 32 columns per wave; the inner sums take four (k, k + 2, k + 4, k + 6) terms per
+    // lane and trip with all eight LDS reads issued before the first product (a plain loop waits out one LDS latency per term:
+    // 430 us instead of 40).  A wave only reads inverse entries it wrote itself: wave-level ordering is enough.
+    const int c = tid >> 1, h = tid & 1;
+    const int c0 = __builtin_amdgcn_readfirstlane(c & ~31);
+    if (h == 0 && c < nb) Xs[c * CHOL_LS + c] = 1.f / Ls[c * CHOL_LS + c];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (int i = c0 + 1; i < nb; ++i) {
+      const float* lrow = Ls + i * CHOL_LS;
+      float acc0 = 0.f, acc1 = 0.f;
+      for (int k = c0 + h; k < i; k += 8) {
+        float lv[4], xv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int kk = min(k + 2 * u, CHOL_NB - 1);
+          lv[u] = lrow[kk];
+          xv[u] = Xs[kk * CHOL_LS + min(c, CHOL_NB - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int kk = k + 2 * u;
+          const float t = (kk < i && kk >= c) ? lv[u] * xv[u] : 0.f;   // (entries never written are masked, not multiplied)
+          if (u & 1) acc1 += t; else acc0 += t;
+        }
+      }
+      float acc = acc0 + acc1;
+      acc += __shfl_xor(acc, 1);
+      if (h == 0 && i > c && c < nb) Xs[i * CHOL_LS + c] = -acc / lrow[i];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < nb * nb; idx += 256) {
+    const int i = idx / nb, c = idx - i * nb;
+    linv_out[(long)i * CHOL_NB + c] = (c <= i) ? Xs[i * CHOL_LS + c] : 0.f;
+  }
+}
+
+// Panel of the blocked factorisation, in place: P (rest x nb, row-major, leading dimension ld) <- P L^{-T}, with
+// linv = row-major L^{-1} (leading dimension CHOL_NB); a compact copy (leading dimension CHOL_NB) feeds the trailing update.
+// 16 rows per workgroup; the inverse passes through LDS in four slabs of 32 inner indices, transposed on the way in.
+// 25 KB of LDS: the chain runs next to large products on the main stream, and a workgroup that asks for more than the
+// CU has left waits for one of theirs to retire (measured: a 83 KB version of this kernel and a 132 KB fused
+// factor-and-invert kernel were faster alone and 11 ms slower in the step).
+// (rocBLAS picks 16 x 16 / 128 x 64 macro tiles for this 128-deep product: 130-180 us per panel.)
+#define CHOL_PR 16
+__global__ __launch_bounds__(256) void chol_panel_kernel(float* __restrict__ P, long ld, int rest, int nb, const float* __restrict__ linv,
+                                                         float* __restrict__ compact) {
+  __shared__ float Ps[CHOL_PR][CHOL_LS];
+  __shared__ float Lt[32][CHOL_LS];            // Lt[k - k0][j] = linv[j][k]
+  const int tid = threadIdx.x;
+  const int r0 = blockIdx.x * CHOL_PR;
+  for (int idx = tid; idx < CHOL_PR * CHOL_NB; idx += 256) {
+    const int r = idx / CHOL_NB, k = idx - r * CHOL_NB;
+    Ps[r][k] = (r0 + r < rest && k < nb) ? P[(long)(r0 + r) * ld + k] : 0.f;
+  }
+  const int ty = tid >> 5, tx = tid & 31;   // rows 2 ty, 2 ty + 1; columns tx + 32 q
+  float acc[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
+  for (int k0 = 0; k0 < nb; k0 += 32) {
+    __syncthreads();
+    for (int idx = tid; idx < CHOL_NB * 32; idx += 256) {
+      const int j = idx >> 5, kk = idx & 31;
+      Lt[kk][j] = (j < nb && k0 + kk <= j) ? linv[(long)j * CHOL_NB + k0 + kk] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int kk = 0; kk < 32; ++kk) {
+      const float p0 = Ps[2 * ty][k0 + kk], p1 = Ps[2 * ty + 1][k0 + kk];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const float lv = Lt[kk][tx + 32 * b];
+        acc[0][b] += p0 * lv;
+        acc[1][b] += p1 * lv;
+      }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int r = r0 + 2 * ty + a;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int j = tx + 32 * b;
+      if (r < rest && j < nb) {
+        P[(long)r * ld + j] = acc[a][b];
+        compact[(long)r * CHOL_NB + j] = acc[a][b];
+      }
+    }
+  }
 }
 
 // Blocked right-looking Cholesky of the row-major lower triangle (= column-major upper, A = U^T U):
@@ -1262,15 +1376,37 @@ static int chol_lower_rm(pmd_ctx* ctx, int n, float* A, long ld, int* info, floa
   PMD_HIP(ctx, hipMemsetAsync(info, 0, sizeof(int), ctx->stream));
   PMD_HIP(ctx, hipMemsetAsync(linv, 0, sizeof(float) * CHOL_NB * CHOL_NB, ctx->stream));
   const float one = 1.f, minus1 = -1.f;
+  // PMD_CHOL_CHAIN=rocblas: the earlier chain (strtri on the block, panel by sgemm into a copy) for A/B runs
+  static int own_chain = -1;
+  if (own_chain < 0) { const char* e = getenv("PMD_CHOL_CHAIN"); own_chain = (e && !strcmp(e, "rocblas")) ? 0 : 1; }
+  // PMD_CHOL_FUSED=1: factor and invert the diagonal block in one launch (132 KB of LDS: faster alone, slower next to the
+  // large products of the main stream, see chol_panel_kernel)
+  static int fused_inv = -1;
+  if (fused_inv < 0) { const char* e = getenv("PMD_CHOL_FUSED"); fused_inv = (e && !strcmp(e, "1")) ? 1 : 0; }
+  const size_t lds = 2 * (size_t)CHOL_NB * CHOL_LS * sizeof(float);
+  if (own_chain && fused_inv)
+    PMD_HIP(ctx, hipFuncSetAttribute((const void*)potf2_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   for (int k0 = 0; k0 < n; k0 += CHOL_NB) {
     const int nb = std::min(CHOL_NB, n - k0);
     float* D = A + (long)k0 * ld + k0;
-    hipLaunchKernelGGL(potf2_block_kernel, dim3(1), dim3(256), 0, ctx->stream, D, ld, nb, k0, info, abs_last_pivot ? n : -1);
-    PMD_LAUNCH_CHECK(ctx, "potf2_block_kernel");
     const int rest = n - k0 - nb;
+    const bool fused = own_chain && fused_inv && rest > 0;
+    hipLaunchKernelGGL(potf2_block_kernel, dim3(1), dim3(256), fused ? lds : 0, ctx->stream, D, ld, nb, k0, info, abs_last_pivot ? n : -1,
+                       fused ? linv : (float*)nullptr);
+    PMD_LAUNCH_CHECK(ctx, "potf2_block_kernel");
     if (rest <= 0) break;
     float* P = A + (long)(k0 + nb) * ld + k0;        // row-major rest x nb  ==  column-major nb x rest
     float* T22 = A + (long)(k0 + nb) * ld + (k0 + nb);
+    if (own_chain) {
+      // L21 = A21 L_kk^{-T} in place (+ a compact copy for the trailing update)
+      if (!fused)
+        PMD_BLAS(ctx, rocblas_strtri(ctx->blas, rocblas_fill_upper, rocblas_diagonal_non_unit, nb, D, (rocblas_int)ld, linv, CHOL_NB));
+      hipLaunchKernelGGL(chol_panel_kernel, dim3((rest + CHOL_PR - 1) / CHOL_PR), dim3(256), 0, ctx->stream, P, ld, rest, nb, linv, tmp);
+      PMD_LAUNCH_CHECK(ctx, "chol_panel_kernel");
+      PMD_BLAS(ctx, rocblas_ssyrk(ctx->blas, rocblas_fill_upper, rocblas_operation_transpose, rest, nb, &minus1, tmp, CHOL_NB, &one,
+                                  T22, (rocblas_int)ld));
+      continue;
+    }
     // L21 = A21 L_kk^{-T}: invert the 128 x 128 block (column-major upper view of the row-major lower block)
     // and multiply - rocBLAS' strsm spends ~20 small launches per panel on the same thing
     PMD_BLAS(ctx, rocblas_strtri(ctx->blas, rocblas_fill_upper, rocblas_diagonal_non_unit, nb, D, (rocblas_int)ld, linv, CHOL_NB));
