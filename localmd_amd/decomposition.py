@@ -24,7 +24,6 @@ import datetime
 import math
 import sys
 import os
-import threading
 import time
 from typing import Callable, Optional
 
@@ -1052,37 +1051,21 @@ def localmd_decomposition(
                 ev_c.record(main)
                 lap("orthogonalize", t0)
                 t0 = time.perf_counter()
-                # The Cholesky call blocks its caller (it reports success through a host flag, and its large products
-                # read operand maxima back), and so does the M^T Z product below: a helper thread drives the side
-                # stream, so that the two chains are enqueued - and run - next to each other.
+                Z = build_z(everywhere=not shard)
+                W1 = torch.zeros((m_eff, T), dtype=torch.float32, device=ctx.device)
+                if nrow > 0:
+                    Mt = Mt_buf[:m_eff * nrow].view(m_eff, nrow)
+                    ctx.call("pmd_gemm", 0, 0, m_eff, T, nrow, 1.0, ptr(Mt), nrow, ptr(Z[row_lo:]), T, 0.0, ptr(W1), T)
+                lap("v_projection", t0)
+                t0 = time.perf_counter()
+                # (driving the side stream from a helper thread, so that the chain is enqueued before the blocking read-back
+                # inside the M^T Z product, was tried: no gain at config 3 - the chain is bound by CU availability next to
+                # the product, not by when it is enqueued - and erratic 40-70 ms waits at config 2; not kept)
                 sc = ctx.side()
                 sc.stream.wait_event(ev_c)
                 with torch.cuda.stream(sc.stream):
                     ws2 = sc.workspace(lib.pmd_chol_inverse_workspace_bytes(m_eff))
-                side_err = []
-
-                def cholesky_job():
-                    try:
-                        torch.cuda.set_device(ctx.device)   # the current device is per thread
-                        with torch.cuda.stream(sc.stream):
-                            sc.call("pmd_chol_inverse", ptr(Et_dev), m_eff, m_cols, abs_last, C.byref(ok_c), ptr(ws2), ws2.numel())
-                    except BaseException as exc:   # re-raised on the calling thread below
-                        side_err.append(exc)
-
-                side_thread = threading.Thread(target=cholesky_job, name="pmd-cholesky")
-                side_thread.start()
-                try:
-                    Z = build_z(everywhere=not shard)
-                    W1 = torch.zeros((m_eff, T), dtype=torch.float32, device=ctx.device)
-                    if nrow > 0:
-                        Mt = Mt_buf[:m_eff * nrow].view(m_eff, nrow)
-                        ctx.call("pmd_gemm", 0, 0, m_eff, T, nrow, 1.0, ptr(Mt), nrow, ptr(Z[row_lo:]), T, 0.0, ptr(W1), T)
-                finally:
-                    side_thread.join()
-                if side_err:
-                    raise side_err[0]
-                lap("v_projection", t0)
-                t0 = time.perf_counter()
+                    sc.call("pmd_chol_inverse", ptr(Et_dev), m_eff, m_cols, abs_last, C.byref(ok_c), ptr(ws2), ws2.numel())
                 ev_e = torch.cuda.Event()
                 ev_e.record(sc.stream)
                 main.wait_event(ev_e)

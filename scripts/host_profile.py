@@ -24,3 +24,7 @@ pr.enable(); step(); torch.cuda.synchronize(); pr.disable()
 st = io.StringIO()
 pstats.Stats(pr, stream=st).sort_stats("tottime").print_stats(28)
 print(st.getvalue())
+import time
+for rep in range(6):
+    torch.cuda.synchronize(); t0 = time.perf_counter(); step(); torch.cuda.synchronize()
+    print(f"step {rep}: {1e3 * (time.perf_counter() - t0):.1f} ms", flush=True)
