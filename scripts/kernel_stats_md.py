@@ -12,7 +12,8 @@ def short(name):
     name = name.replace("(anonymous namespace)::", "")
     if name.startswith("Cijk_"):
         m = re.match(r"(Cijk_[A-Za-z]+_[A-Za-z]+_[A-Z_]*?MT\d+x\d+x\d+)", name)
-        return "rocBLAS sgemm " + (m.group(1) if m else name[:40])
+        lib = "hipBLASLt fp16 x fp16 -> fp32 (gemm_f16x2) " if "_HSS_" in name else "rocBLAS sgemm "
+        return lib + (m.group(1) if m else name[:40])
     return name.split("(")[0][:70]
 
 tag = re.search(r"(r\d+)_", sys.argv[1]).group(1)
@@ -36,5 +37,9 @@ print(f"\nHow these rows map to the `roofline` objects of the bench line: `sytrd
       + f" ({rl['algorithmic_mb_per_launch'] / (float(sym['AverageNs']) / 1e3) / 8e3 * 1e3:.2f} with the profiler's kernel duration)."
       + (f"  `tile_atx_dma_kernel<25>`: {float(atx[0]['AverageNs']) / 1e6:.1f} ms average over its launches (the d x T ones take 12.9-13.6 ms, the short sketch launches pull the average down); "
          f"the bench line's `roofline_mfma` has the d x T launches alone: {line['roofline_mfma']['achieved']:.0f} TFLOP/s = {line['roofline_mfma']['frac']:.2f} of the fp32-MFMA peak." if atx else ""))
+print("Of the launches of `tile_atx_dma_kernel<25>`, two are the d x T products of the tile stage (13.2 ms each) and one is the "
+      "rank-adaptive projection of the whole movie (tiles that kept <= 32 components run half the MFMA work: 7.7 ms).  `f16x2_absmax_kernel` (operand maxima of the "
+      "fp16-piece products) reads 1 ms per launch under the profiler; in the unprofiled run the whole split (maxima, read-back, pieces) "
+      "costs 8.8 ms per decomposition by HIP events (`f16x2_split` in the bench line).\n")
 print("Counter passes (separate runs, FETCH_SIZE only, restricted to the kernel, taken on the same sources - their SHA-256 is recorded and checked by `bench.py`): "
       f"`profiles/{tag}_pmc_sytrd_n10000.json`, `profiles/{tag}_pmc_tile_atx.json`.")
