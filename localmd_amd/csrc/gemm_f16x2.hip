@@ -115,36 +115,44 @@ __global__ __launch_bounds__(256) void f16x2_absmax_final_kernel(const unsigned*
 
 struct half4_t { _Float16 x, y, z, w; };
 
-__device__ inline void f16x2_pieces(float v, _Float16& a, _Float16& b) {
+__device__ inline void f16x2_pieces(float v, _Float16& a, _Float16& b, _Float16& c) {
   a = (_Float16)v;
-  b = (_Float16)((v - (float)a) * 2048.f);
+  const float r = (v - (float)a) * 2048.f;       // exact: the residual has at most 13 significant bits
+  b = (_Float16)r;
+  c = (_Float16)((r - (float)b) * 2048.f);       // exact: at most 2 bits are left - three pieces hold an fp32 number exactly
 }
 
+// h3 != NULL: third piece (X 2^-e = h1 + 2^-11 h2 + 2^-22 h3, exact)
 __global__ __launch_bounds__(256) void f16x2_split_kernel(const float* __restrict__ x, int rows, int cols, long ld, int vec, float scale,
-                                                          _Float16* __restrict__ h1, _Float16* __restrict__ h2, long ldh) {
+                                                          _Float16* __restrict__ h1, _Float16* __restrict__ h2, _Float16* __restrict__ h3,
+                                                          long ldh) {
   const int c4 = vec ? cols / 4 : 0;   // (ldh is a multiple of 8: the pieces' rows are 16-byte aligned too)
   for (int r = blockIdx.x; r < rows; r += gridDim.x) {
     const float* row = x + (long)r * ld;
     _Float16* o1 = h1 + (long)r * ldh;
     _Float16* o2 = h2 + (long)r * ldh;
+    _Float16* o3 = h3 ? h3 + (long)r * ldh : nullptr;
     const float4* row4 = reinterpret_cast<const float4*>(row);
     half4_t* p1 = reinterpret_cast<half4_t*>(o1);
     half4_t* p2 = reinterpret_cast<half4_t*>(o2);
+    half4_t* p3 = reinterpret_cast<half4_t*>(o3);
     for (int c = threadIdx.x; c < c4; c += 256) {
       const float4 v = row4[c];
-      half4_t a, b;
-      f16x2_pieces(v.x * scale, a.x, b.x);
-      f16x2_pieces(v.y * scale, a.y, b.y);
-      f16x2_pieces(v.z * scale, a.z, b.z);
-      f16x2_pieces(v.w * scale, a.w, b.w);
+      half4_t a, b, d;
+      f16x2_pieces(v.x * scale, a.x, b.x, d.x);
+      f16x2_pieces(v.y * scale, a.y, b.y, d.y);
+      f16x2_pieces(v.z * scale, a.z, b.z, d.z);
+      f16x2_pieces(v.w * scale, a.w, b.w, d.w);
       p1[c] = a;
       p2[c] = b;
+      if (o3) p3[c] = d;
     }
     for (int c = 4 * c4 + threadIdx.x; c < cols; c += 256) {
-      _Float16 a, b;
-      f16x2_pieces(row[c] * scale, a, b);
+      _Float16 a, b, d;
+      f16x2_pieces(row[c] * scale, a, b, d);
       o1[c] = a;
       o2[c] = b;
+      if (o3) o3[c] = d;
     }
   }
 }
@@ -199,12 +207,12 @@ static inline int vec_ok(const void* p, int cols, long ld) { (void)cols; return 
 
 long pmd_f16x2_ld(int cols) { return pmd_round_up(cols, 8); }
 
-size_t pmd_f16x2_bytes(int rows, int cols) { return 2 * sizeof(_Float16) * (size_t)rows * pmd_f16x2_ld(cols) + 256; }
+size_t pmd_f16x2_bytes(int rows, int cols, int pieces) { return pieces * sizeof(_Float16) * (size_t)rows * pmd_f16x2_ld(cols) + 256; }
 
 // Splits up to two operands with ONE read-back of their maxima.  h1 of operand i = (char*)buf_i, h2 follows it.
 // *usable = 0 when an operand cannot take the path (Inf / NaN, all zero, subnormal maximum): nothing was written then.
 int pmd_f16x2_split(pmd_ctx* ctx, int count, const float* const* X, const int* rows, const int* cols, const long* ld, void* const* buf,
-                    pmd_f16x2_op* ops, int* usable) {
+                    pmd_f16x2_op* ops, int* usable, int pieces) {
   RUN_OK(ensure_state(ctx));
   f16x2_state* st = state_of(ctx);
   *usable = 0;
@@ -230,12 +238,14 @@ int pmd_f16x2_split(pmd_ctx* ctx, int count, const float* const* X, const int* r
     const long ldh = pmd_f16x2_ld(cols[i]);
     _Float16* h1 = (_Float16*)buf[i];
     _Float16* h2 = h1 + (size_t)rows[i] * ldh;
+    _Float16* h3 = pieces == 3 ? h2 + (size_t)rows[i] * ldh : nullptr;
     ops[i].h1 = h1;
     ops[i].h2 = h2;
+    ops[i].h3 = h3;
     ops[i].ld = ldh;
     const int blocks = rows[i] < 8192 ? rows[i] : 8192;
     hipLaunchKernelGGL(f16x2_split_kernel, dim3(blocks), dim3(256), 0, ctx->stream, X[i], rows[i], cols[i], ld[i], vec_ok(X[i], cols[i], ld[i]),
-                       ldexpf(1.f, -ops[i].e), h1, h2, ldh);
+                       ldexpf(1.f, -ops[i].e), h1, h2, h3, ldh);
   }
   PMD_LAUNCH_CHECK(ctx, "f16x2_split_kernel");
   *usable = 1;
@@ -289,8 +299,21 @@ int pmd_f16x2_matmul(pmd_ctx* ctx, int tA, int tB, int m, int n, int k, float al
   if (!p->ok) return PMD_OK;
   pmd_prof_scope prof__(ctx, "gemm_f16x2");
   const float a_main = alpha * ldexpf(1.f, a.e + b.e), a_small = alpha * ldexpf(1.f, a.e + b.e - 11), one = 1.f;
-  if (!std::isfinite(a_main) || a_small == 0.f) return PMD_OK;   // scales outside fp32: the fp32 path decides what that means
-  PMD_LT(ctx, hipblasLtMatmul(st->lt, p->desc, &a_small, b.h2, p->la, a.h1, p->lb, &beta, C, p->lc, C, p->lc, &p->algo, st->ws, st->ws_bytes,
+  const float a_tiny = alpha * ldexpf(1.f, a.e + b.e - 22);
+  const bool six = a.h3 && b.h3;
+  if (!std::isfinite(a_main) || a_small == 0.f || (six && a_tiny == 0.f)) return PMD_OK;   // scales outside fp32: the fp32 path decides
+  if (six) {
+    // three exact pieces per operand: A1 B3 + A3 B1 + A2 B2 (2^-22), then the three products below; what is dropped
+    // (A2 B3, A3 B2, A3 B3) is 2^-33 of the product - every kept product is exact, only the fp32 accumulation rounds
+    PMD_LT(ctx, hipblasLtMatmul(st->lt, p->desc, &a_tiny, b.h3, p->la, a.h1, p->lb, &beta, C, p->lc, C, p->lc, &p->algo, st->ws, st->ws_bytes,
+                                ctx->stream));
+    PMD_LT(ctx, hipblasLtMatmul(st->lt, p->desc, &a_tiny, b.h1, p->la, a.h3, p->lb, &one, C, p->lc, C, p->lc, &p->algo, st->ws, st->ws_bytes,
+                                ctx->stream));
+    PMD_LT(ctx, hipblasLtMatmul(st->lt, p->desc, &a_tiny, b.h2, p->la, a.h2, p->lb, &one, C, p->lc, C, p->lc, &p->algo, st->ws, st->ws_bytes,
+                                ctx->stream));
+  }
+  const float* beta1 = six ? &one : &beta;
+  PMD_LT(ctx, hipblasLtMatmul(st->lt, p->desc, &a_small, b.h2, p->la, a.h1, p->lb, beta1, C, p->lc, C, p->lc, &p->algo, st->ws, st->ws_bytes,
                               ctx->stream));
   PMD_LT(ctx, hipblasLtMatmul(st->lt, p->desc, &a_small, b.h1, p->la, a.h2, p->lb, &one, C, p->lc, C, p->lc, &p->algo, st->ws, st->ws_bytes,
                               ctx->stream));
@@ -336,7 +359,7 @@ int pmd_gemm_f16x2(pmd_ctx* ctx, int transA, int transB, int m, int n, int k, fl
                    float beta, float* C, long ldc, int* done) {
   *done = 0;
   const int a_rows = transA ? k : m, a_cols = transA ? m : k, b_rows = transB ? n : k, b_cols = transB ? k : n;
-  const size_t na = pmd_f16x2_bytes(a_rows, a_cols), nb = pmd_f16x2_bytes(b_rows, b_cols);
+  const size_t na = pmd_f16x2_bytes(a_rows, a_cols, 2), nb = pmd_f16x2_bytes(b_rows, b_cols, 2);
   void* w = nullptr;
   RUN_OK(pmd_split_scratch(ctx, na + nb, &w));
   if (!w) return PMD_OK;
@@ -346,7 +369,7 @@ int pmd_gemm_f16x2(pmd_ctx* ctx, int transA, int transB, int m, int n, int k, fl
   void* buf[2] = {w, (char*)w + na};
   pmd_f16x2_op ops[2];
   int usable = 0;
-  RUN_OK(pmd_f16x2_split(ctx, 2, X, rows, cols, ld, buf, ops, &usable));
+  RUN_OK(pmd_f16x2_split(ctx, 2, X, rows, cols, ld, buf, ops, &usable, 2));
   if (!usable) return PMD_OK;
   return pmd_f16x2_matmul(ctx, transA, transB, m, n, k, alpha, ops[0], ops[1], beta, C, ldc, done);
 }

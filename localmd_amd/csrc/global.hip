@@ -1447,16 +1447,21 @@ int pmd_gram_mtgm_impl(pmd_ctx* ctx, const float* M, int rows, int m, long ldm, 
   // fp16-piece products (gemm_f16x2.hip): both operands are split ONCE, the row blocks are views of the pieces
   bool pieces = false;
   pmd_f16x2_op ma, gb;
-  // This product stays on the fp32 path by default (PMD_F16X2_MTGM=1 opts in).  C is singular by construction on the
-  // R > frames route (its last pivot is the null direction, 3e-12 of the mean diagonal on the headline fixture) and the
-  // Cholesky step needs every other pivot positive: fp32 products are exact before accumulation, two fp16 pieces carry
-  // 22-23 bits, and with them the factorisation of that fixture fails (the route then falls back to the eigenvectors:
-  // s 5.5e-4 / Vt 3.4e-3 against the arbiter instead of 1.1e-4 / 1.5e-3).  Every other large product is insensitive:
-  // the same fixture gives the same figures to three digits with or without the pieces (scripts/debug_headline.py).
+  // This product stays on the fp32 path (PMD_F16X2_MTGM=2 | 3: fp16 pieces per operand, for A/B runs).  C is singular by
+  // construction on the R > frames route (its last pivot is the null direction, 3e-12 of the mean diagonal on the headline
+  // fixture) and the Cholesky step needs every other pivot positive; on that fixture sgemm's C passes and the matrix-core
+  // C does not - with two pieces (22-23 bits per operand) AND with three (an fp32 number exactly; six exact piece products,
+  // only the accumulation rounds): what differs is the accumulation inside the matrix-core kernel, not the split.  The
+  // route then falls back to the eigenvectors (s 5.5e-4 / Vt 3.4e-3 against the arbiter instead of 1.1e-4 / 1.5e-3), so
+  // the 17 ms (three pieces) / 37 ms (two) this product would gain at config 3 are left on the table.
   static int mtgm_pieces = -1;
-  if (mtgm_pieces < 0) { const char* e = getenv("PMD_F16X2_MTGM"); mtgm_pieces = (e && !strcmp(e, "1")) ? 1 : 0; }
+  if (mtgm_pieces < 0) {
+    const char* e = getenv("PMD_F16X2_MTGM");
+    mtgm_pieces = e ? atoi(e) : 0;
+    if (mtgm_pieces != 2 && mtgm_pieces != 3) mtgm_pieces = 0;
+  }
   if (mtgm_pieces && pmd_f16x2_wanted(ctx, std::min(bs, m), m, rows)) {
-    const size_t na = pmd_f16x2_bytes(m, rows), nb = pmd_f16x2_bytes(rows, m);
+    const size_t na = pmd_f16x2_bytes(m, rows, mtgm_pieces), nb = pmd_f16x2_bytes(rows, m, mtgm_pieces);
     void* w = nullptr;
     RUN(pmd_split_scratch(ctx, na + nb, &w));
     const float* X[2] = {Mt, GM};
@@ -1466,7 +1471,7 @@ int pmd_gram_mtgm_impl(pmd_ctx* ctx, const float* M, int rows, int m, long ldm, 
     void* buf[2] = {w, (char*)w + na};
     pmd_f16x2_op ops[2];
     int usable = 0;
-    RUN(pmd_f16x2_split(ctx, 2, X, xr, xc, xl, buf, ops, &usable));
+    RUN(pmd_f16x2_split(ctx, 2, X, xr, xc, xl, buf, ops, &usable, mtgm_pieces));
     if (usable) { pieces = true; ma = ops[0]; gb = ops[1]; }
     }
   }
@@ -1476,6 +1481,7 @@ int pmd_gram_mtgm_impl(pmd_ctx* ctx, const float* M, int rows, int m, long ldm, 
       pmd_f16x2_op a = ma;
       a.h1 += (long)i0 * ma.ld;
       a.h2 += (long)i0 * ma.ld;
+      if (a.h3) a.h3 += (long)i0 * ma.ld;
       int done = 0;
       RUN(pmd_f16x2_matmul(ctx, 0, 0, nr, i0 + nr, rows, 1.f, a, gb, 0.f, C + (long)i0 * ldc, ldc, &done));
       if (done) continue;

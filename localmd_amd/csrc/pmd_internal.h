@@ -117,14 +117,15 @@ int pmd_gemm_k_chunk(int k);
 struct pmd_f16x2_op {
   const _Float16* h1;
   const _Float16* h2;
+  const _Float16* h3;   // third piece (2^-22), or NULL
   long ld;
   int e;
 };
 bool pmd_f16x2_wanted(const pmd_ctx* ctx, int m, int n, int k);
 long pmd_f16x2_ld(int cols);
-size_t pmd_f16x2_bytes(int rows, int cols);
+size_t pmd_f16x2_bytes(int rows, int cols, int pieces);
 int pmd_f16x2_split(pmd_ctx* ctx, int count, const float* const* X, const int* rows, const int* cols, const long* ld, void* const* buf,
-                    pmd_f16x2_op* ops, int* usable);
+                    pmd_f16x2_op* ops, int* usable, int pieces);
 int pmd_f16x2_matmul(pmd_ctx* ctx, int tA, int tB, int m, int n, int k, float alpha, const pmd_f16x2_op& a, const pmd_f16x2_op& b, float beta,
                      float* C, long ldc, int* done);
 int pmd_gemm_f16x2(pmd_ctx* ctx, int transA, int transB, int m, int n, int k, float alpha, const float* A, long lda, const float* B, long ldb,
