@@ -228,6 +228,9 @@ int pmd_projected_svd_factored(pmd_ctx* ctx, const float* M, int Rc, int m, long
 /* The two halves of pmd_orthogonalize_chol, for callers that shard the rows of M over ranks: the partial
  * C = M[rows]^T GM[rows] (row-major lower block triangle; all-reduce it), then C -> Et in place. */
 size_t pmd_gram_mtgm_workspace_bytes(int rows, int m);
+/* leading dimension of the transposed copy M^T (m x rows) that pmd_gram_mtgm leaves at the start of its workspace (a multiple
+ * of 64 floats; the host driver reuses the copy for the M^T Z product) */
+long pmd_gram_mtgm_ld(int rows);
 int pmd_gram_mtgm(pmd_ctx* ctx, const float* M, int rows, int m, long ldm, const float* GM, long ldgm, float* C, long ldc,
                   void* ws, size_t ws_bytes);
 size_t pmd_chol_inverse_workspace_bytes(int m);

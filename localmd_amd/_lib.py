@@ -76,6 +76,7 @@ SIGNATURES = {
     "pmd_projected_svd_factored": (c_i, [c_p, c_p, c_i, c_i, c_l, c_p, c_i, c_l, c_p, c_i, c_l, c_p, c_l, c_p, c_p, c_l,
                                          c_p, c_l, c_p, c_p, c_i, c_p, c_sz]),
     "pmd_gram_mtgm_workspace_bytes": (c_sz, [c_i, c_i]),
+    "pmd_gram_mtgm_ld": (c_l, [c_i]),
     "pmd_gram_mtgm": (c_i, [c_p, c_p, c_i, c_i, c_l, c_p, c_l, c_p, c_l, c_p, c_sz]),
     "pmd_chol_inverse_workspace_bytes": (c_sz, [c_i]),
     "pmd_chol_inverse": (c_i, [c_p, c_p, c_i, c_l, c_i, C.POINTER(c_i), c_p, c_sz]),

@@ -404,6 +404,7 @@ int pmd_orthogonalize_chol(pmd_ctx* ctx, const float* M, int Rc, int m, long ldm
 }
 size_t pmd_orthogonalize_chol_workspace_bytes(int Rc, int m) { return pmd_orthogonalize_chol_workspace_bytes_impl(Rc, m); }
 size_t pmd_gram_mtgm_workspace_bytes(int rows, int m) { return pmd_gram_mtgm_workspace_bytes_impl(rows, m); }
+long pmd_gram_mtgm_ld(int rows) { return pmd_gram_mtgm_ld_impl(rows); }
 int pmd_gram_mtgm(pmd_ctx* ctx, const float* M, int rows, int m, long ldm, const float* GM, long ldgm, float* C, long ldc,
                   void* ws, size_t ws_bytes) {
   CTX_CHECK(ctx);

@@ -1105,7 +1105,7 @@ int pmd_orthogonalize_factored_impl(pmd_ctx* ctx, const float* M, int Rc, int m,
 
 size_t pmd_projected_svd_factored_workspace_bytes_impl(int Rc, int m, int rp, int T) {
   return (size_t)m * T * sizeof(float) + (size_t)rp * T * sizeof(float) + (size_t)m * rp * sizeof(float) +
-         (size_t)m * Rc * sizeof(float) + pmd_projected_svd_workspace_bytes_impl(1, rp, T) + 16384;
+         (size_t)m * pmd_round_up(Rc, 64) * sizeof(float) + pmd_projected_svd_workspace_bytes_impl(1, rp, T) + 16384;
 }
 
 // M: Rc x m; Et: rp x m; Z: Rc x T.  Outputs R_out (Rc x nk), s (nk), Vt (nk x T), nk = min(rp, T);
@@ -1120,7 +1120,8 @@ int pmd_projected_svd_factored_impl(pmd_ctx* ctx, const float* M, int Rc, int m,
   float* Vp = Vp_out ? Vp_out : ar.take_n<float>((size_t)rp * T);
   const long ldv = Vp_out ? ldvp : T;
   float* X1 = X1_out ? X1_out : ar.take_n<float>((size_t)m * rp);
-  float* Mt = ar.take_n<float>((size_t)m * Rc);
+  const long ldt = pmd_round_up(Rc, 64);   // (rows of the transposed copy on 256-byte boundaries, see pmd_gram_mtgm_ld_impl)
+  float* Mt = ar.take_n<float>((size_t)m * ldt);
   const size_t sub_bytes = pmd_projected_svd_workspace_bytes_impl(1, rp, T);
   void* sub = ar.take(sub_bytes);
   if (ar.overflow) return pmd_fail(ctx, PMD_ERR_WORKSPACE, "pmd_projected_svd_factored", "workspace too small");
@@ -1128,8 +1129,8 @@ int pmd_projected_svd_factored_impl(pmd_ctx* ctx, const float* M, int Rc, int m,
   // reach half the rate of the plain ones at K = Rc ~ 5e4 (72 vs 147 TFLOP/s, scripts/gemm_probe.hip),
   // and the copy is one 2 x 4 Rc m byte pass
   if (!W1_in) {
-    RUN(launch_transpose(ctx, M, ldm, Rc, m, Mt, Rc));
-    RUN(pmd_gemm_rm(ctx, 0, 0, m, T, Rc, 1.f, Mt, Rc, Z, ldz, 0.f, W1, T));      // M^T Z
+    RUN(launch_transpose(ctx, M, ldm, Rc, m, Mt, ldt));
+    RUN(pmd_gemm_rm(ctx, 0, 0, m, T, Rc, 1.f, Mt, ldt, Z, ldz, 0.f, W1, T));      // M^T Z
   }
   // (W1_in: the caller has formed M^T Z already, e.g. as an all-reduced sum of per-rank row-range partials)
   // Cholesky route: Et is lower triangular (zeros above the diagonal), strmm does half the work in fp32; where the full
@@ -1426,21 +1427,26 @@ __global__ void tril_mask_kernel(float* __restrict__ A, long ld, int n) {
 }
 
 size_t pmd_orthogonalize_chol_workspace_bytes_impl(int Rc, int m) {
-  return std::max((size_t)m * Rc * sizeof(float), pmd_chol_inverse_workspace_bytes_impl(m)) + ((size_t)m + CHOL_NB) * CHOL_NB * sizeof(float) + 16384;
+  return std::max(pmd_gram_mtgm_workspace_bytes_impl(Rc, m), pmd_chol_inverse_workspace_bytes_impl(m)) + ((size_t)m + CHOL_NB) * CHOL_NB * sizeof(float) + 16384;
 }
 
 // C (row-major lower block triangle, the part the Cholesky step reads) = M^T GM over `rows` rows of both.
 // With the tile rows sharded over ranks every rank passes its own row range and the partial C are all-reduced.
-size_t pmd_gram_mtgm_workspace_bytes_impl(int rows, int m) { return (size_t)m * rows * sizeof(float) + 4096; }
+// The transposed copy M^T (m x rows) at the start of the workspace has leading dimension pmd_gram_mtgm_ld(rows): a multiple of
+// 64 floats.  (With ld = rows = 113 305 at BASELINE config 4 every row of the copy started off a 16-byte boundary and rocBLAS
+// fell back to element-wise loads: 51 TFLOP/s for this product instead of 130.)
+long pmd_gram_mtgm_ld_impl(int rows) { return pmd_round_up(rows, 64); }
+size_t pmd_gram_mtgm_workspace_bytes_impl(int rows, int m) { return (size_t)m * pmd_gram_mtgm_ld_impl(rows) * sizeof(float) + 4096; }
 
 int pmd_gram_mtgm_impl(pmd_ctx* ctx, const float* M, int rows, int m, long ldm, const float* GM, long ldgm, float* C,
                        long ldc, void* ws, size_t ws_bytes) {
   if (rows <= 0) return PMD_OK;
   pmd_arena ar(ws, ws_bytes);
-  float* Mt = ar.take_n<float>((size_t)m * rows);
+  const long ldt = pmd_gram_mtgm_ld_impl(rows);
+  float* Mt = ar.take_n<float>((size_t)m * ldt);
   if (ar.overflow) return pmd_fail(ctx, PMD_ERR_WORKSPACE, "pmd_gram_mtgm", "workspace too small");
   // row blocks C[i0:i0+bs, 0:i0+bs] = Mt[i0:i0+bs, :] GM[:, 0:i0+bs]  (3/5 of the flops at 5 blocks)
-  RUN(launch_transpose(ctx, M, ldm, rows, m, Mt, rows));
+  RUN(launch_transpose(ctx, M, ldm, rows, m, Mt, ldt));
   const char* cbenv = getenv("PMD_C_BLOCKS");
   const int nblk = cbenv ? std::max(1, atoi(cbenv)) : 5;  // 2/3/4/5/6/8/12/16 blocks at m = 10^4: 70/64/57/52/59/58/60/67 ms
   const int bs = std::max(256, ((m + nblk - 1) / nblk + 255) / 256 * 256);
@@ -1467,7 +1473,7 @@ int pmd_gram_mtgm_impl(pmd_ctx* ctx, const float* M, int rows, int m, long ldm, 
     const float* X[2] = {Mt, GM};
     if (w) {
     const int xr[2] = {m, rows}, xc[2] = {rows, m};
-    const long xl[2] = {rows, ldgm};
+    const long xl[2] = {ldt, ldgm};
     void* buf[2] = {w, (char*)w + na};
     pmd_f16x2_op ops[2];
     int usable = 0;
@@ -1489,7 +1495,7 @@ int pmd_gram_mtgm_impl(pmd_ctx* ctx, const float* M, int rows, int m, long ldm, 
     }
     const int keep = ctx->gemm_split;
     if (!mtgm_pieces) ctx->gemm_split = 0;
-    const int rc = pmd_gemm_rm(ctx, 0, 0, nr, i0 + nr, rows, 1.f, Mt + (long)i0 * rows, rows, GM, ldgm, 0.f, C + (long)i0 * ldc, ldc);
+    const int rc = pmd_gemm_rm(ctx, 0, 0, nr, i0 + nr, rows, 1.f, Mt + (long)i0 * ldt, ldt, GM, ldgm, 0.f, C + (long)i0 * ldc, ldc);
     ctx->gemm_split = keep;
     RUN(rc);
   }

@@ -189,6 +189,7 @@ int pmd_psvd_vp_gram_impl(pmd_ctx* ctx, const float* Et, int rp, int m, long lde
 size_t pmd_psvd_finish_workspace_bytes_impl(int rp);
 int pmd_psvd_finish_impl(pmd_ctx* ctx, float* C, long ldc, int rp, const float* Vp, int nc, long ldv, float* W_out, long ldw, float* s_out,
                          float* Vt_out, long ldvt, void* ws, size_t ws_bytes);
+long pmd_gram_mtgm_ld_impl(int rows);
 size_t pmd_gram_mtgm_workspace_bytes_impl(int rows, int m);
 int pmd_gram_mtgm_impl(pmd_ctx* ctx, const float* M, int rows, int m, long ldm, const float* GM, long ldgm, float* C,
                        long ldc, void* ws, size_t ws_bytes);

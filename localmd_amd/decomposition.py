@@ -1054,8 +1054,8 @@ def localmd_decomposition(
                 Z = build_z(everywhere=not shard)
                 W1 = torch.zeros((m_eff, T), dtype=torch.float32, device=ctx.device)
                 if nrow > 0:
-                    Mt = Mt_buf[:m_eff * nrow].view(m_eff, nrow)
-                    ctx.call("pmd_gemm", 0, 0, m_eff, T, nrow, 1.0, ptr(Mt), nrow, ptr(Z[row_lo:]), T, 0.0, ptr(W1), T)
+                    ld_mt = int(lib.pmd_gram_mtgm_ld(nrow))   # (rows of the transposed copy are padded to 64 floats)
+                    ctx.call("pmd_gemm", 0, 0, m_eff, T, nrow, 1.0, ptr(Mt_buf), ld_mt, ptr(Z[row_lo:]), T, 0.0, ptr(W1), T)
                 lap("v_projection", t0)
                 t0 = time.perf_counter()
                 # (driving the side stream from a helper thread, so that the chain is enqueued before the blocking read-back
