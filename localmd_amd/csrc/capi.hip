@@ -24,6 +24,7 @@ int pmd_ctx_create(int device, void* hip_stream, pmd_ctx** out) {
   ctx->scratch2 = nullptr;
   ctx->scratch2_bytes = 0;
   ctx->atx_ranks = nullptr;
+  ctx->atx_rows = 0;
   ctx->split_ws = nullptr;
   ctx->split_ws_bytes = 0;
   {

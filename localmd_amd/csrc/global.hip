@@ -632,7 +632,10 @@ int pmd_bg_project_impl(pmd_ctx* ctx, const float* xs, long D, int T, long ld, c
     const int kc = (K - k0 < 64) ? K - k0 : 64;
     hipLaunchKernelGGL(block_basis_kernel, dim3(nblk * (BGP_BLK / 256)), dim3(256), 0, ctx->stream, basis + k0, D, kc, At, K);
     PMD_LAUNCH_CHECK(ctx, "block_basis_kernel");
-    RUN(pmd_launch_tile_atx(ctx, xs, ld, nullptr, 0, BGP_BLK, BGP_BLK, At, 64L * BGP_BLK, BGP_BLK, part, 64L * ldt, ldt, nblk, T, 8));
+    ctx->atx_rows = kc;   // (<= 16 columns - the default rank is 15 - run on one row tile: a quarter of the MFMA work)
+    const int rc_atx = pmd_launch_tile_atx(ctx, xs, ld, nullptr, 0, BGP_BLK, BGP_BLK, At, 64L * BGP_BLK, BGP_BLK, part, 64L * ldt, ldt, nblk, T, 8);
+    ctx->atx_rows = 0;
+    RUN(rc_atx);
     // sum the block partials row by row into out[k][0:T]
     for (int k = 0; k < kc; ++k)
       RUN(pmd_launch_reduce_slices(ctx, part + (long)k * ldt, 0, 64L * ldt, nblk, T, out + (long)(k0 + k) * ldo, 0, 1));

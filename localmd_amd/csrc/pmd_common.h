@@ -36,6 +36,7 @@ struct pmd_ctx {
   float* tables;  // device: Hann window + FFT twiddles, see prep.hip
   char err[512];
   const char* atx_label;             // profiling name of the next tile_atx launches (NULL: "tile_atx")
+  int atx_rows;                      // rows of A that carry data in the next tile_atx launches (0: all 64)
   const int* atx_ranks;              // per-tile ranks of the next tile_atx launches (projection: rows >= rank of A are zero), or NULL
   void* scratch;                     // library-owned device scratch of the eigensolver (sytrd.hip)
   size_t scratch_bytes;

@@ -24,8 +24,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // lane slot kk <-> row q = 16*J + 4*kk + s, so one float4 of A feeds four MFMAs and the LDS
 // rows of one 32-lane group sit 4 rows = 16 banks apart (row stride TC+4 floats): conflict-free.
 // ------------------------------------------------------------------------------------------
-template <int KJW, int KS, int NS>
-__global__ __launch_bounds__(256 * KS * NS) void tile_atx_kernel(const float* __restrict__ X, long ldx,
+// MT = row tiles of A that carry data (4: all 64 rows, one row tile per wave and K slice; 1: rows < 16 only - the background
+// projection with its default 15 columns - where the waves are K slices of the ONE row tile: a quarter of the MFMA work,
+// rows >= 16 of Out are not written).
+template <int KJW, int KS, int NS, int MT = 4>
+__global__ __launch_bounds__(64 * MT * KS * NS) void tile_atx_kernel(const float* __restrict__ X, long ldx,
                                                             const int* __restrict__ pix, int pix_stride,
                                                             long row0_stride, int d,
                                                             const float* __restrict__ A, long a_tile_stride, int a_ld,
@@ -38,19 +41,21 @@ __global__ __launch_bounds__(256 * KS * NS) void tile_atx_kernel(const float* __
   // NS = 2: a second group of four waves takes the second 16-frame N tile, so every SIMD hosts two
   // waves whose LDS refills, barriers and stores overlap with the other one's MFMAs.
   static_assert(NS == 1 || KS == 1, "the N split is only built for KS = 1");
-  constexpr int NTHREADS = 256 * KS * NS;
+  static_assert(MT == 4 || (MT == 1 && NS == 1), "one row tile: K slices only");
+  constexpr int NTHREADS = 64 * MT * KS * NS;
+  constexpr int RED = (KS - 1) * MT * 512;   // floats of K-split scratch
   constexpr int QUADS = TC / 4;
   constexpr int NPRE = (DPAD * QUADS + NTHREADS - 1) / NTHREADS;
   // two LDS buffers (one barrier per chunk) whenever they fit next to the K-split scratch
-  constexpr bool DB = (2 * DPAD * LSTR + (KS - 1) * 2048 + 4) * 4 <= 160 * 1024;
+  constexpr bool DB = (2 * DPAD * LSTR + RED + 4) * 4 <= 160 * 1024;
   constexpr int NBUF = DB ? 2 : 1;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* red = lds + NBUF * DPAD * LSTR;
-  constexpr int TRASH = NBUF * DPAD * LSTR + (KS - 1) * 2048;  // 16-byte slot nobody reads
+  constexpr int TRASH = NBUF * DPAD * LSTR + RED;  // 16-byte slot nobody reads
 
   const int tile = pmd_xcd_tile();
   const int tid = threadIdx.x, lane = tid & 63, wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform, and known to be)
-  const int mt = wid & 3, ks = (NS == 1) ? (wid >> 2) : 0, nh = (NS == 1) ? 0 : (wid >> 2);
+  const int mt = (MT == 4) ? (wid & 3) : 0, ks = (NS == 1) ? ((MT == 4) ? (wid >> 2) : wid) : 0, nh = (NS == 1) ? 0 : (wid >> 2);
   const int n16 = lane & 15, kk = lane >> 4;
   const int kz = blockIdx.z;           // grid-level K split (d > DPAD)
   const int qbase = kz * DPAD;
@@ -159,7 +164,7 @@ __global__ __launch_bounds__(256 * KS * NS) void tile_atx_kernel(const float* __
     if (KS > 1) {
       // sum the K slices of the waves that share an M tile
       if (ks > 0) {
-        float* r = red + (((ks - 1) * 4 + mt) * 2) * 256 + lane;
+        float* r = red + (((ks - 1) * MT + mt) * 2) * 256 + lane;
 #pragma unroll
         for (int i = 0; i < 4; ++i) { r[i * 64] = acc0[i]; r[256 + i * 64] = acc1[i]; }
       }
@@ -167,7 +172,7 @@ __global__ __launch_bounds__(256 * KS * NS) void tile_atx_kernel(const float* __
       if (ks == 0) {
 #pragma unroll
         for (int o = 1; o < KS; ++o) {
-          const float* r = red + (((o - 1) * 4 + mt) * 2) * 256 + lane;
+          const float* r = red + (((o - 1) * MT + mt) * 2) * 256 + lane;
 #pragma unroll
           for (int i = 0; i < 4; ++i) { acc0[i] += r[i * 64]; acc1[i] += r[256 + i * 64]; }
         }
@@ -379,14 +384,16 @@ static int launch_atx_dma(pmd_ctx* ctx, const float* X, long ldx, const int* pix
   return PMD_OK;
 }
 
-template <int KJW, int KS, int NS>
+template <int KJW, int KS, int NS, int MT = 4>
 static int launch_atx_variant(pmd_ctx* ctx, const float* X, long ldx, const int* pix, int pix_stride, long row0_stride,
                               int d, const float* A, long a_tile_stride, int a_ld, float* Out, long out_tile_stride,
                               long ldo, int n_tiles, int T, int slices, int kz) {
   constexpr int DPAD = 16 * KJW * KS;
-  constexpr bool DB = (2 * DPAD * 36 + (KS - 1) * 2048 + 4) * 4 <= 160 * 1024;
-  const size_t lds = (size_t)((DB ? 2 : 1) * DPAD * 36 + (KS > 1 ? (KS - 1) * 4 * 2 * 256 : 0) + 4) * sizeof(float);
-  auto kern = tile_atx_kernel<KJW, KS, NS>;
+  constexpr int RED = (KS - 1) * MT * 512;
+  constexpr bool DB = (2 * DPAD * 36 + RED + 4) * 4 <= 160 * 1024;
+  const size_t lds = (size_t)((DB ? 2 : 1) * DPAD * 36 + RED + 4) * sizeof(float);
+  static_assert(((DB ? 2 : 1) * DPAD * 36 + RED + 4) * 4 <= 160 * 1024, "LDS budget");
+  auto kern = tile_atx_kernel<KJW, KS, NS, MT>;
   PMD_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   const int n_chunks = (T + 31) / 32;
   if (slices < 1) slices = 1;
@@ -394,7 +401,7 @@ static int launch_atx_variant(pmd_ctx* ctx, const float* X, long ldx, const int*
   const int cps = (n_chunks + slices - 1) / slices;
   const int ny = (n_chunks + cps - 1) / cps;
   // tiles ride on gridDim.x (limit 2^31-1)
-  hipLaunchKernelGGL(kern, dim3(n_tiles, ny, kz), dim3(256 * KS * NS), lds, ctx->stream, X, ldx, pix, pix_stride,
+  hipLaunchKernelGGL(kern, dim3(n_tiles, ny, kz), dim3(64 * MT * KS * NS), lds, ctx->stream, X, ldx, pix, pix_stride,
                      row0_stride, d, A, a_tile_stride, a_ld, Out, out_tile_stride, ldo, n_chunks, cps);
   PMD_LAUNCH_CHECK(ctx, "tile_atx_kernel");
   return PMD_OK;
@@ -431,6 +438,10 @@ int pmd_launch_tile_atx(pmd_ctx* ctx, const float* X, long ldx, const int* pix, 
       return launch_atx_dma<25>(ctx, X, ldx, pix, pix_stride, row0_stride, d, A, a_tile_stride, a_ld, Out, out_tile_stride,
                                 ldo, n_tiles, T, slices, ctx->atx_ranks);
   }
+  // rows < 16 only (ctx->atx_rows, set by the background projection) on a 1024-pixel tile: eight K slices of one row tile
+  if (ctx->atx_rows > 0 && ctx->atx_rows <= 16 && v.kjw == 32 && v.ks == 2 && kz == 1)
+    return launch_atx_variant<8, 8, 1, 1>(ctx, X, ldx, pix, pix_stride, row0_stride, d, A, a_tile_stride, a_ld, Out, out_tile_stride, ldo,
+                                          n_tiles, T, slices, kz);
   ATX_CASE(16, 1, 2)
   ATX_CASE(25, 1, 1)
   ATX_CASE(32, 1, 1)
@@ -525,6 +536,103 @@ __global__ __launch_bounds__(256) void tile_xbt_kernel(const float* __restrict__
   }
 }
 
+// The same with B staged through LDS (round 3).  In the form above every wave loads all four 16-component tiles of B for
+// every 16-frame group - the four waves of a workgroup fetch the same 4 KB four times, 27 GB of the 68 GB the kernel pulls
+// through L2 per launch at config 3.  Here wave w fetches component tile w only and publishes it in LDS (two 4 KB buffers,
+// one barrier per group: 112 MFMAs = 3 600 cycles apart); every wave reads its four operand fragments from there.
+template <int MPW>
+__global__ __launch_bounds__(256) void tile_xbt_lds_kernel(const float* __restrict__ X, long ldx,
+                                                           const int* __restrict__ pix, int pix_stride, long row0_stride,
+                                                           int d, const float* __restrict__ B, long b_tile_stride, long ldb,
+                                                           float* __restrict__ S, long s_tile_stride, long s_slice_stride,
+                                                           int s_ld, int n_groups_total, int groups_per_slice) {
+  __shared__ f32x4 bs[2][4][64];
+  const int tile = pmd_xcd_tile();
+  const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int n16 = lane & 15, kk = lane >> 4;
+  const int m0 = (blockIdx.z * 4 + wid) * MPW;  // first M tile of this wave
+  const int g_begin = blockIdx.y * groups_per_slice;
+  const int g_end = min(n_groups_total, g_begin + groups_per_slice);
+
+  const float* xrow[MPW];
+  bool mvalid[MPW];
+  float rmask[MPW];
+#pragma unroll
+  for (int i = 0; i < MPW; ++i) {
+    const int q = 16 * (m0 + i) + n16;
+    mvalid[i] = 16 * (m0 + i) < d;  // wave-uniform
+    const int qc = min(q, d - 1);
+    const long row = pix ? (long)pix[(long)tile * pix_stride + qc] : (long)tile * row0_stride + qc;
+    xrow[i] = X + row * ldx + 4 * kk;
+    rmask[i] = (q < d) ? 1.f : 0.f;
+  }
+  // this wave's share of B: component tile `wid`
+  const float* bmine = B + (long)tile * b_tile_stride + (long)(16 * wid + n16) * ldb + 4 * kk;
+
+  f32x4 acc[MPW][4];
+#pragma unroll
+  for (int i = 0; i < MPW; ++i)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // (every wave runs the loop - also one whose pixel tiles all lie beyond d: it carries a quarter of B and the barriers)
+  if (g_begin < g_end) {
+    f32x4 a0[MPW], a1[MPW], bnext;
+    auto load_x = [&](f32x4* a, int g) {
+      const long t = (long)g * 16;
+#pragma unroll
+      for (int i = 0; i < MPW; ++i)
+        if (mvalid[i]) a[i] = *reinterpret_cast<const f32x4*>(xrow[i] + t);
+    };
+    auto compute = [&](const f32x4* a, int buf) {
+      f32x4 b[4];
+#pragma unroll
+      for (int n = 0; n < 4; ++n) b[n] = bs[buf][n][lane];
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < MPW; ++i)
+          if (mvalid[i]) {
+            const float av = a[i][s] * rmask[i];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b[n][s], acc[i][n], 0, 0, 0);
+          }
+    };
+    bs[0][wid][lane] = *reinterpret_cast<const f32x4*>(bmine + (long)g_begin * 16);
+    load_x(a0, g_begin);
+    __syncthreads();
+    int g = g_begin;
+    for (; g + 1 < g_end; g += 2) {
+      // group g from (a0, buffer 0); group g + 1 from (a1, buffer 1)
+      bnext = *reinterpret_cast<const f32x4*>(bmine + (long)(g + 1) * 16);
+      load_x(a1, g + 1);
+      compute(a0, 0);
+      bs[1][wid][lane] = bnext;
+      __syncthreads();
+      const bool more = g + 2 < g_end;   // uniform over the workgroup
+      if (more) {
+        bnext = *reinterpret_cast<const f32x4*>(bmine + (long)(g + 2) * 16);
+        load_x(a0, g + 2);
+      }
+      compute(a1, 1);
+      if (more) bs[0][wid][lane] = bnext;
+      __syncthreads();
+    }
+    if (g < g_end) compute(a0, 0);
+  }
+
+  float* sp = S + (long)tile * s_tile_stride + (long)blockIdx.y * s_slice_stride;
+#pragma unroll
+  for (int i = 0; i < MPW; ++i) {
+    if (!mvalid[i]) continue;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      float* o = sp + (long)(16 * n + n16) * s_ld + 16 * (m0 + i) + 4 * kk;
+      *reinterpret_cast<f32x4*>(o) = acc[i][n];
+    }
+  }
+}
+
 // S rows have s_ld floats (>= 16*ceil(d/16)); slices partition the frame range.
 int pmd_launch_tile_xbt(pmd_ctx* ctx, const float* X, long ldx, const int* pix, int pix_stride, long row0_stride, int d,
                         const float* B, long b_tile_stride, long ldb, float* S, long s_tile_stride,
@@ -547,12 +655,20 @@ int pmd_launch_tile_xbt(pmd_ctx* ctx, const float* X, long ldx, const int* pix, 
                                   (size_t)(slices_asked - slices) * s_slice_stride * sizeof(float), (size_t)n_tiles, ctx->stream));
   }
   // M tiles per wave: spread small tiles over the four waves, 7 per wave (112 accumulator VGPRs) at most
+  // PMD_XBT_LDS=0: every wave loads all of B itself (the form of rounds 1-2, A/B runs)
+  static int blds = -1;
+  if (blds < 0) { const char* e = getenv("PMD_XBT_LDS"); blds = (e && !strcmp(e, "0")) ? 0 : 1; }
 #define XBT_LAUNCH(MPW_)                                                                                              \
   {                                                                                                                   \
     const int mblocks = (mtiles + 4 * MPW_ - 1) / (4 * MPW_);                                                         \
-    hipLaunchKernelGGL(tile_xbt_kernel<MPW_>, dim3(n_tiles, slices, mblocks), dim3(256), 0, ctx->stream, X, ldx, pix, \
-                       pix_stride, row0_stride, d, B, b_tile_stride, ldb, S, s_tile_stride, s_slice_stride, s_ld,     \
-                       n_groups, gps);                                                                                \
+    if (blds)                                                                                                         \
+      hipLaunchKernelGGL(tile_xbt_lds_kernel<MPW_>, dim3(n_tiles, slices, mblocks), dim3(256), 0, ctx->stream, X, ldx, pix, \
+                         pix_stride, row0_stride, d, B, b_tile_stride, ldb, S, s_tile_stride, s_slice_stride, s_ld,   \
+                         n_groups, gps);                                                                              \
+    else                                                                                                              \
+      hipLaunchKernelGGL(tile_xbt_kernel<MPW_>, dim3(n_tiles, slices, mblocks), dim3(256), 0, ctx->stream, X, ldx, pix, \
+                         pix_stride, row0_stride, d, B, b_tile_stride, ldb, S, s_tile_stride, s_slice_stride, s_ld,   \
+                         n_groups, gps);                                                                              \
   }
   if (mtiles <= 4) XBT_LAUNCH(1)
   else if (mtiles <= 8) XBT_LAUNCH(2)
