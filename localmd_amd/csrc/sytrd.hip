@@ -703,6 +703,67 @@ __global__ __launch_bounds__(512, CWT == 1024 ? 2 : 4) void sytrd_symv_kernel(co
 // resident, 16 consecutive floats per lane group); rocBLAS' ssyr2k spends several launches per call on this.
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// The same update with the panel operands staged through LDS (round 3).  In the form below every lane fetches its MFMA
+// operands one float at a time (ten 4-byte loads per eight MFMAs) and the four waves of a workgroup fetch the same column-side
+// fragments four times.  Here the workgroup copies the 64 x 64 blocks of V and W it needs (row side and column side, two
+// halves of 32 panel rows, coalesced 256-byte rows) into LDS once and every wave reads its fragments from there: 2.5 x less
+// traffic through L2, a third of the load instructions.  Same MFMAs in the same order: bit-identical results.
+__global__ __launch_bounds__(256) void sytrd_rank2k_lds_kernel(float* __restrict__ A, long lda, int n, int ts, int j0, int nbc,
+                                                               const float* __restrict__ W, long ldw) {
+  constexpr int LS = 68;
+  __shared__ float sv_c[32][LS], sw_c[32][LS], sv_r[32][LS], sw_r[32][LS];   // [panel row][position]: row side (c), column side (r)
+  const int I = blockIdx.y, J = blockIdx.x;
+  if (J < I) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
+  const int n16 = lane & 15, kk = lane >> 4;
+  const int cb = ts + 64 * I, r0 = ts + 64 * J;
+  const int c0 = cb + 16 * wave;
+  const float* V = A + (long)j0 * lda;
+  f32x4 acc[4];
+#pragma unroll
+  for (int jn = 0; jn < 4; ++jn) acc[jn] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int lp = tid & 63, lk = tid >> 6;   // loader: position lp, panel rows lk, lk + 4, ...
+  const int pc = min(cb + lp, n - 1), pr = min(r0 + lp, n - 1);
+  for (int h = 0; h < 2; ++h) {
+    if (h) __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = 32 * h + lk + 4 * u;
+      const bool in = k < nbc;
+      const long kc = in ? k : 0;   // unconditional loads on a valid row, masked below
+      const float v1 = V[kc * lda + pc], w1 = W[kc * ldw + pc], v2 = V[kc * lda + pr], w2 = W[kc * ldw + pr];
+      sv_c[lk + 4 * u][lp] = in ? v1 : 0.f;
+      sw_c[lk + 4 * u][lp] = in ? w1 : 0.f;
+      sv_r[lk + 4 * u][lp] = in ? v2 : 0.f;
+      sw_r[lk + 4 * u][lp] = in ? w2 : 0.f;
+    }
+    __syncthreads();
+    if (c0 < n) {
+#pragma unroll
+      for (int k0 = 0; k0 < 32; k0 += 4) {
+        const int k = k0 + kk;
+        const float a1 = sv_c[k][16 * wave + n16], a2 = sw_c[k][16 * wave + n16];
+#pragma unroll
+        for (int jn = 0; jn < 4; ++jn) {
+          const float b1 = sw_r[k][16 * jn + n16], b2 = sv_r[k][16 * jn + n16];
+          acc[jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[jn], 0, 0, 0);
+          acc[jn] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, b2, acc[jn], 0, 0, 0);
+        }
+      }
+    }
+  }
+  if (c0 >= n) return;
+#pragma unroll
+  for (int jn = 0; jn < 4; ++jn) {
+    const int col = r0 + 16 * jn + n16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = c0 + 4 * kk + i;
+      if (row < n && col < n && col >= row) A[(long)row * lda + col] -= acc[jn][i];
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void sytrd_rank2k_kernel(float* __restrict__ A, long lda, int n, int ts, int j0, int nbc,
                                                            const float* __restrict__ W, long ldw) {
   const int I = blockIdx.y, J = blockIdx.x;
@@ -926,7 +987,10 @@ int pmd_sytrd_impl(pmd_ctx* ctx, int n, float* A, long lda, float* d, float* e, 
                                    A + (long)ts * lda + ts, (rocblas_int)lda));
     } else {
       const int nt = (n - ts + 63) / 64;
-      hipLaunchKernelGGL(sytrd_rank2k_kernel, dim3(nt, nt), dim3(256), 0, st, A, lda, n, ts, j0, nbc, B.W, B.ldw);
+      static int r2k_lds = -1;   // PMD_RANK2K=direct: operands straight from the panels (the form of rounds 1-2)
+      if (r2k_lds < 0) { const char* e = getenv("PMD_RANK2K"); r2k_lds = (e && !strcmp(e, "direct")) ? 0 : 1; }
+      if (r2k_lds) hipLaunchKernelGGL(sytrd_rank2k_lds_kernel, dim3(nt, nt), dim3(256), 0, st, A, lda, n, ts, j0, nbc, B.W, B.ldw);
+      else hipLaunchKernelGGL(sytrd_rank2k_kernel, dim3(nt, nt), dim3(256), 0, st, A, lda, n, ts, j0, nbc, B.W, B.ldw);
       PMD_LAUNCH_CHECK(ctx, "sytrd_rank2k_kernel");
     }
   }
