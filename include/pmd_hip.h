@@ -290,6 +290,11 @@ int pmd_transpose_affine(pmd_ctx* ctx, const float* src, long lds_, long rows, i
 int pmdk_tile_atx(pmd_ctx* ctx, const float* X, long ldx, const int* pix, int pix_stride, long row0_stride, int d,
                   const float* A, long a_tile_stride, int a_ld, float* Out, long out_tile_stride, long ldo, int n_tiles,
                   int T, int slices);
+/* the same with the number of rows of A that carry data (rows >= `rows` are zero): <= 16 rows on 1024-pixel tiles and 33-50 rows
+ * on 257-400-pixel tiles run specialised kernels that leave the output rows beyond the last 16-row tile they touch unwritten */
+int pmdk_tile_atx_rows(pmd_ctx* ctx, const float* X, long ldx, const int* pix, int pix_stride, long row0_stride, int d,
+                       const float* A, long a_tile_stride, int a_ld, float* Out, long out_tile_stride, long ldo, int n_tiles,
+                       int T, int slices, int rows);
 int pmdk_tile_xbt(pmd_ctx* ctx, const float* X, long ldx, const int* pix, int pix_stride, long row0_stride, int d,
                   const float* B, long b_tile_stride, long ldb, float* S, long s_tile_stride, long s_slice_stride,
                   int s_ld, int n_tiles, int T, int slices);

@@ -96,6 +96,7 @@ SIGNATURES = {
     "pmd_gemm_split_active": (c_i, [c_p, c_i, c_i, c_i]),
     "pmd_gemm": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_l, c_p, c_l, c_f, c_p, c_l]),
     "pmdk_tile_atx": (c_i, [c_p, c_p, c_l, c_p, c_i, c_l, c_i, c_p, c_l, c_i, c_p, c_l, c_l, c_i, c_i, c_i]),
+    "pmdk_tile_atx_rows": (c_i, [c_p, c_p, c_l, c_p, c_i, c_l, c_i, c_p, c_l, c_i, c_p, c_l, c_l, c_i, c_i, c_i, c_i]),
     "pmdk_tile_xbt": (c_i, [c_p, c_p, c_l, c_p, c_i, c_l, c_i, c_p, c_l, c_l, c_p, c_l, c_l, c_i, c_i, c_i, c_i]),
     "pmdk_tile_gram": (c_i, [c_p, c_p, c_l, c_l, c_i, c_i, c_i, c_p]),
     "pmdk_tile_rowmix": (c_i, [c_p, c_p, c_l, c_l, c_p, c_l, c_i, c_i, c_p, c_l, c_l, c_i, c_i]),

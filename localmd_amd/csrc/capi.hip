@@ -452,6 +452,15 @@ int pmdk_tile_atx(pmd_ctx* ctx, const float* X, long ldx, const int* pix, int pi
   CTX_CHECK(ctx);
   return pmd_launch_tile_atx(ctx, X, ldx, pix, pix_stride, row0_stride, d, A, a_tile_stride, a_ld, Out, out_tile_stride, ldo, n_tiles, T, slices);
 }
+int pmdk_tile_atx_rows(pmd_ctx* ctx, const float* X, long ldx, const int* pix, int pix_stride, long row0_stride, int d,
+                       const float* A, long a_tile_stride, int a_ld, float* Out, long out_tile_stride, long ldo, int n_tiles,
+                       int T, int slices, int rows) {
+  CTX_CHECK(ctx);
+  ctx->atx_rows = rows;
+  const int rc = pmd_launch_tile_atx(ctx, X, ldx, pix, pix_stride, row0_stride, d, A, a_tile_stride, a_ld, Out, out_tile_stride, ldo, n_tiles, T, slices);
+  ctx->atx_rows = 0;
+  return rc;
+}
 int pmdk_tile_xbt(pmd_ctx* ctx, const float* X, long ldx, const int* pix, int pix_stride, long row0_stride, int d,
                   const float* B, long b_tile_stride, long ldb, float* S, long s_tile_stride, long s_slice_stride,
                   int s_ld, int n_tiles, int T, int slices) {

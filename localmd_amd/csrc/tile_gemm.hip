@@ -212,6 +212,10 @@ __global__ __launch_bounds__(64 * MT * KS * NS) void tile_atx_kernel(const float
 // is XORed with 4 * ((row >> 2) & 1) - applied on the global-address side by the loader and on the read side
 // by the MFMA operand fetch - so the four K slots of a lane group never share a bank.
 // Rows q >= dloc load the tile's first row (finite values meeting zero columns of A).
+// (Round 3: a three-row-tile form for the default 50 components - rows 0-47 as 3 row tiles x 2 frame tiles x 2 pixel halves on
+// the matrix cores, rows 48-49 on the vector units, partial sums exchanged through LDS: 22 % fewer MFMAs, a quarter of the LDS
+// operand reads - was built, verified against fp64 and measured at 13.5 ms against 13.4 ms for this kernel (14.6 ms without its
+// vector-unit part, 13.9 ms without its stores): neither the MFMA count nor the stores bound this kernel; not kept.)
 // ------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void* pmd_lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* pmd_gbl_ptr_t;

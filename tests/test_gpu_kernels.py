@@ -120,6 +120,33 @@ def test_tiles_project_ranked(gpu_ctx, d, T):
             assert np.isnan(got[t, 32:]).all() or np.abs(got[t, 32:] - ref[t, 32:]).max() / scale < 2e-6, (t, r)
 
 
+@pytest.mark.parametrize("d,T,r", [(1024, 333, 15), (1024, 64, 7), (1024, 1000, 16), (400, 1000, 50), (1024, 200, 17)])
+def test_tile_atx_row_hint(gpu_ctx, d, T, r):
+    """pmdk_tile_atx_rows: the kernel specialised on the number of rows of A that carry data - one row tile, eight pixel slices,
+    for <= 16 rows on 1024-pixel tiles (the background projection) - against fp64; the rows it skips stay untouched, and a
+    hint no kernel is specialised for changes nothing."""
+    ctx, torch = gpu_ctx, _t()
+    lib = ctx.lib
+    rng = np.random.default_rng(11)
+    n_tiles, rows = 7, max(2 * d, 900)
+    ld, dpad = lib.pmd_time_ld(T), lib.pmd_tile_dpad(d)
+    X = np.zeros((rows, ld), dtype=np.float32)
+    X[:, :T] = rng.standard_normal((rows, T)).astype(np.float32)
+    pix = np.stack([rng.choice(rows, size=d, replace=False) for _ in range(n_tiles)]).astype(np.int32)
+    A = np.zeros((n_tiles, 64, dpad), dtype=np.float32)
+    A[:, :r, :d] = rng.standard_normal((n_tiles, r, d)).astype(np.float32)
+    Out = torch.full((n_tiles, 64, ld), np.nan, dtype=torch.float32, device=ctx.device)
+    Xd, Ad, pd = dev(ctx, X), dev(ctx, A), dev(ctx, pix)
+    ctx.call("pmdk_tile_atx_rows", P(Xd), ld, P(pd), d, d, d, P(Ad), 64 * dpad, dpad, P(Out), 64 * ld, ld, n_tiles, T, 3, r)
+    ctx.sync()
+    got = Out.cpu().numpy()[:, :, :T]
+    ref = np.einsum("ncq,nqt->nct", A[:, :, :d].astype(np.float64), X[pix][:, :, :T].astype(np.float64))
+    scale = np.abs(ref).max()
+    assert np.abs(got[:, :r] - ref[:, :r]).max() / scale < 2e-6, (d, T, r)
+    rest = got[:, r:]
+    assert np.all(np.isnan(rest) | (np.abs(np.nan_to_num(rest)) < 1e-6 * scale)), "rows beyond the hint: untouched or zero"
+
+
 def _xbt_case(ctx, d, T, n_tiles, rows, slices, shared_b=False, seed=1):
     torch = _t()
     lib = ctx.lib
