@@ -726,6 +726,46 @@ def test_gemm_fp16_pieces(kind, monkeypatch):
         ref_ctx.close()
 
 
+def test_gemm_large_product_takes_the_fp16_piece_path(gpu_ctx):
+    """A product above the library's own size gate (>= 100 GFLOP, no dimension below 256) runs from fp16 pieces without any
+    option set; sampled entries against fp64, next to the sgemm path of a second context (PMD_GEMM_SPLIT=0)."""
+    torch = _t()
+    from localmd_amd._lib import Context
+    import os
+
+    ctx = gpu_ctx
+    m, n, k = 1024, 1536, 40000
+    assert ctx.lib.pmd_gemm_split_active(ctx.handle, m, n, k) == 1
+    g = torch.Generator(device=ctx.device).manual_seed(7)
+    a = torch.randn((m, k), device=ctx.device, generator=g) * torch.logspace(-3, 0, k, device=ctx.device)[None, :]
+    b = torch.randn((k, n), device=ctx.device, generator=g).abs_()
+    c = torch.empty((m, n), device=ctx.device)
+    ctx.call("pmd_gemm", 0, 0, m, n, k, 1.0, P(a), k, P(b), n, 0.0, P(c), n)
+    ctx.sync()
+    rows = torch.arange(0, m, 37, device=ctx.device)
+    ref = (a[rows].double() @ b.double()).cpu().numpy()
+    err = np.linalg.norm(c[rows].cpu().numpy() - ref) / np.linalg.norm(ref)
+    old = os.environ.get("PMD_GEMM_SPLIT")
+    os.environ["PMD_GEMM_SPLIT"] = "0"
+    try:
+        ref_ctx = Context(0)
+    finally:
+        if old is None:
+            del os.environ["PMD_GEMM_SPLIT"]
+        else:
+            os.environ["PMD_GEMM_SPLIT"] = old
+    try:
+        c2 = torch.empty((m, n), device=ctx.device)
+        ref_ctx.call("pmd_gemm", 0, 0, m, n, k, 1.0, P(a), k, P(b), n, 0.0, P(c2), n)
+        ref_ctx.sync()
+        err_sgemm = np.linalg.norm(c2[rows].cpu().numpy() - ref) / np.linalg.norm(ref)
+    finally:
+        ref_ctx.close()
+    # (measured: 4.7e-7 from pieces, 1.2e-6 from the chunked sgemm path)
+    assert err < 1e-6 and err < 1.5 * err_sgemm, (err, err_sgemm)
+    assert not torch.equal(c, c2), "the two contexts were meant to take different paths"
+
+
 @pytest.mark.parametrize("ta,tb", [(0, 0), (1, 0), (0, 1), (1, 1)])
 def test_gemm_long_inner_dimension_split(gpu_ctx, ta, tb):
     """pmd_gemm with few output tiles and a very long inner dimension takes the split-K path (strided-batched slices +
