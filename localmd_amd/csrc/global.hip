@@ -1456,13 +1456,17 @@ int pmd_gram_mtgm_impl(pmd_ctx* ctx, const float* M, int rows, int m, long ldm, 
   // fp16-piece products (gemm_f16x2.hip): both operands are split ONCE, the row blocks are views of the pieces
   bool pieces = false;
   pmd_f16x2_op ma, gb;
-  // This product stays on the fp32 path (PMD_F16X2_MTGM=2 | 3: fp16 pieces per operand, for A/B runs).  C is singular by
+  // This product stays on the fp32 path (PMD_F16X2_MTGM=3 | 2: fp16 pieces per operand, for A/B runs).  C is singular by
   // construction on the R > frames route (its last pivot is the null direction, 3e-12 of the mean diagonal on the headline
-  // fixture) and the Cholesky step needs every other pivot positive; on that fixture sgemm's C passes and the matrix-core
-  // C does not - with two pieces (22-23 bits per operand) AND with three (an fp32 number exactly; six exact piece products,
-  // only the accumulation rounds): what differs is the accumulation inside the matrix-core kernel, not the split.  The
-  // route then falls back to the eigenvectors (s 5.5e-4 / Vt 3.4e-3 against the arbiter instead of 1.1e-4 / 1.5e-3), so
-  // the 17 ms (three pieces) / 37 ms (two) this product would gain at config 3 are left on the table.
+  // fixture) and the Cholesky step needs every other pivot positive: this is the one product of the stage whose error
+  // structure decides whether the route works at all.  Measured on that fixture (scripts/debug_headline.py): two pieces per
+  // operand (22-23 bits) fail the factorisation or pass it with wrong factors (s off by 0.57); THREE pieces hold an fp32
+  // number exactly, six of the nine piece products (down to 2^-22; the rest is 2^-33) are exact products accumulated in
+  // fp32 - sgemm's own arithmetic - and then the length of the accumulation chain decides: chunks of 2048 / 3072 inner
+  // indices pass with the figures of the fp32 path (s 1.06e-4 / 1.13e-4, Vt 9.5e-4 / 1.2e-3 against the arbiter; sgemm,
+  // chunks of 2048: 1.11e-4, 1.2-1.5e-3), chunks of 4096 and more fail.  With three pieces and the fp32 path's chunk length
+  // the product takes 42 ms against 52 at config 3 - and 870 ms against 690 at BASELINE config 4, where 56 chunks x 6
+  // products x 5 row blocks each re-read and re-write a 330 MB block of C.  Not the default.
   static int mtgm_pieces = -1;
   if (mtgm_pieces < 0) {
     const char* e = getenv("PMD_F16X2_MTGM");
@@ -1491,8 +1495,21 @@ int pmd_gram_mtgm_impl(pmd_ctx* ctx, const float* M, int rows, int m, long ldm, 
       a.h1 += (long)i0 * ma.ld;
       a.h2 += (long)i0 * ma.ld;
       if (a.h3) a.h3 += (long)i0 * ma.ld;
-      int done = 0;
-      RUN(pmd_f16x2_matmul(ctx, 0, 0, nr, i0 + nr, rows, 1.f, a, gb, 0.f, C + (long)i0 * ldc, ldc, &done));
+      // inner dimension in chunks: one fp32 accumulation chain per chunk, of the length the fp32 path uses (the matrix-core
+      // kernel otherwise carries one chain over all of k); PMD_F16X2_MTGM_KCHUNK overrides
+      static int kch_env = -2;
+      if (kch_env == -2) { const char* e = getenv("PMD_F16X2_MTGM_KCHUNK"); kch_env = e ? atoi(e) : -1; }
+      const int kch = kch_env > 0 ? kch_env : (kch_env == 0 ? rows : pmd_gemm_k_chunk(rows));
+      int done = 1;
+      for (int k0 = 0; k0 < rows && done; k0 += kch) {
+        const int kk = std::min(kch, rows - k0);
+        pmd_f16x2_op ak = a, bk = gb;
+        ak.h1 += k0; ak.h2 += k0;
+        if (ak.h3) ak.h3 += k0;
+        bk.h1 += (long)k0 * gb.ld; bk.h2 += (long)k0 * gb.ld;
+        if (bk.h3) bk.h3 += (long)k0 * gb.ld;
+        RUN(pmd_f16x2_matmul(ctx, 0, 0, nr, i0 + nr, kk, 1.f, ak, bk, k0 ? 1.f : 0.f, C + (long)i0 * ldc, ldc, &done));
+      }
       if (done) continue;
       pieces = false;   // (the product below may reuse the scratch that held the pieces)
     }
@@ -1502,6 +1519,9 @@ int pmd_gram_mtgm_impl(pmd_ctx* ctx, const float* M, int rows, int m, long ldm, 
     ctx->gemm_split = keep;
     RUN(rc);
   }
+  // the pieces of both operands are three quarters of M and GM together (27 GB at BASELINE config 4): a scratch of that
+  // size goes back to the device before the eigensolver asks for its workspace
+  if (pieces) RUN(pmd_split_scratch_trim(ctx, (size_t)8 << 30));
   return PMD_OK;
 }
 
