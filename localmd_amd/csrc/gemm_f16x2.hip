@@ -211,6 +211,90 @@ size_t pmd_f16x2_bytes(int rows, int cols, int pieces) { return pieces * sizeof(
 
 // Splits up to two operands with ONE read-back of their maxima.  h1 of operand i = (char*)buf_i, h2 follows it.
 // *usable = 0 when an operand cannot take the path (Inf / NaN, all zero, subnormal maximum): nothing was written then.
+// Exponents e_i with max |X_i| 2^-e_i in [2^13, 2^14) for up to two operands, with ONE read-back.  *usable = 0: an operand
+// cannot take the path (Inf / NaN, all zero, subnormal maximum).
+int pmd_f16x2_exponents(pmd_ctx* ctx, int count, const float* const* X, const int* rows, const int* cols, const long* ld, int* e_out,
+                        int* usable) {
+  RUN_OK(ensure_state(ctx));
+  f16x2_state* st = state_of(ctx);
+  *usable = 0;
+  if (count < 1 || count > 2) return pmd_fail(ctx, PMD_ERR_ARG, "pmd_f16x2_exponents", "one or two operands");
+  for (int i = 0; i < count; ++i) {
+    const int blocks = rows[i] < ABSMAX_BLOCKS ? rows[i] : ABSMAX_BLOCKS;
+    unsigned* part = st->amax_dev + 2 + (size_t)i * ABSMAX_BLOCKS;
+    hipLaunchKernelGGL(f16x2_absmax_kernel, dim3(blocks), dim3(256), 0, ctx->stream, X[i], rows[i], cols[i], ld[i], vec_ok(X[i], cols[i], ld[i]),
+                       part);
+    hipLaunchKernelGGL(f16x2_absmax_final_kernel, dim3(1), dim3(256), 0, ctx->stream, part, blocks, st->amax_dev + i);
+  }
+  PMD_LAUNCH_CHECK(ctx, "f16x2_absmax_kernel");
+  PMD_HIP(ctx, hipMemcpyAsync(st->amax_host, st->amax_dev, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+  PMD_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < count; ++i) {
+    const int be = (int)(st->amax_host[i] >> 23);
+    if (be == 0 || be >= 255) return PMD_OK;
+    e_out[i] = be - 127 - 13;
+  }
+  *usable = 1;
+  return PMD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// "Concatenated" form for products whose accumulator is expensive to revisit (M^T G M: the six piece products of three exact
+// pieces per operand in ONE matrix product).  For a chunk of kk inner indices the operands become
+//     A' (rows x 6 kk) = [ a1 2^-11 | a3 2^-11 | a2 2^-11 | a1 2^-6 | a2 2^-5 | a1 ]
+//     B' (6 kk x cols) = [ b3 2^-11 ; b1 2^-11 ; b2 2^-11 ; b2 2^-5 ; b1 2^-6 ; b1 ]
+// so that A' B' = 2^-22 (a1 b3 + a3 b1 + a2 b2) + 2^-11 (a1 b2 + a2 b1) + a1 b1, the small terms first in the accumulation
+// order.  The scaled copies lose bits only where an entry is below 2^-17 of the largest (2^-22 terms: three bits needed) or
+// 2^-22 of it (2^-11 terms).
+__global__ __launch_bounds__(256) void f16cat_a_kernel(const float* __restrict__ x, int rows, int kk, long ld, float scale, _Float16* __restrict__ out,
+                                                       long ldo) {
+  for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+    const float* row = x + (long)r * ld;
+    _Float16* o = out + (long)r * ldo;
+    for (int c = threadIdx.x; c < kk; c += 256) {
+      _Float16 a, b, d;
+      f16x2_pieces(row[c] * scale, a, b, d);
+      const float fa = (float)a, fb = (float)b, fd = (float)d;
+      o[c] = (_Float16)(fa * (1.f / 2048.f));
+      o[kk + c] = (_Float16)(fd * (1.f / 2048.f));
+      o[2 * kk + c] = (_Float16)(fb * (1.f / 2048.f));
+      o[3 * kk + c] = (_Float16)(fa * (1.f / 64.f));
+      o[4 * kk + c] = (_Float16)(fb * (1.f / 32.f));
+      o[5 * kk + c] = a;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void f16cat_b_kernel(const float* __restrict__ x, int kk, int cols, long ld, float scale, _Float16* __restrict__ out,
+                                                       long ldo) {
+  for (int r = blockIdx.x; r < kk; r += gridDim.x) {
+    const float* row = x + (long)r * ld;
+    for (int c = threadIdx.x; c < cols; c += 256) {
+      _Float16 a, b, d;
+      f16x2_pieces(row[c] * scale, a, b, d);
+      const float fa = (float)a, fb = (float)b, fd = (float)d;
+      out[(long)r * ldo + c] = (_Float16)(fd * (1.f / 2048.f));
+      out[(long)(kk + r) * ldo + c] = (_Float16)(fa * (1.f / 2048.f));
+      out[(long)(2 * kk + r) * ldo + c] = (_Float16)(fb * (1.f / 2048.f));
+      out[(long)(3 * kk + r) * ldo + c] = (_Float16)(fb * (1.f / 32.f));
+      out[(long)(4 * kk + r) * ldo + c] = (_Float16)(fa * (1.f / 64.f));
+      out[(long)(5 * kk + r) * ldo + c] = a;
+    }
+  }
+}
+
+int pmd_f16cat_a(pmd_ctx* ctx, const float* X, int rows, int kk, long ld, int e, _Float16* out, long ldo) {
+  hipLaunchKernelGGL(f16cat_a_kernel, dim3(rows < 4096 ? rows : 4096), dim3(256), 0, ctx->stream, X, rows, kk, ld, ldexpf(1.f, -e), out, ldo);
+  PMD_LAUNCH_CHECK(ctx, "f16cat_a_kernel");
+  return PMD_OK;
+}
+
+int pmd_f16cat_b(pmd_ctx* ctx, const float* X, int kk, int cols, long ld, int e, _Float16* out, long ldo) {
+  hipLaunchKernelGGL(f16cat_b_kernel, dim3(kk < 4096 ? kk : 4096), dim3(256), 0, ctx->stream, X, kk, cols, ld, ldexpf(1.f, -e), out, ldo);
+  PMD_LAUNCH_CHECK(ctx, "f16cat_b_kernel");
+  return PMD_OK;
+}
+
 int pmd_f16x2_split(pmd_ctx* ctx, int count, const float* const* X, const int* rows, const int* cols, const long* ld, void* const* buf,
                     pmd_f16x2_op* ops, int* usable, int pieces) {
   RUN_OK(ensure_state(ctx));
@@ -319,6 +403,21 @@ int pmd_f16x2_matmul(pmd_ctx* ctx, int tA, int tB, int m, int n, int k, float al
                               ctx->stream));
   PMD_LT(ctx, hipblasLtMatmul(st->lt, p->desc, &a_main, b.h1, p->la, a.h1, p->lb, &one, C, p->lc, C, p->lc, &p->algo, st->ws, st->ws_bytes,
                               ctx->stream));
+  *done = 1;
+  return PMD_OK;
+}
+
+// row-major C (m x n) = alpha A B + beta C with fp16 operands as they are (A: m x k, B: k x n)
+int pmd_f16_plain_matmul(pmd_ctx* ctx, int m, int n, int k, float alpha, const _Float16* A, long lda, const _Float16* B, long ldb, float beta,
+                         float* C, long ldc, int* done) {
+  RUN_OK(ensure_state(ctx));
+  f16x2_state* st = state_of(ctx);
+  *done = 0;
+  lt_plan* p = nullptr;
+  RUN_OK(plan_for(ctx, st, 0, 0, m, n, k, lda, ldb, ldc, &p));
+  if (!p->ok) return PMD_OK;
+  pmd_prof_scope prof__(ctx, "gemm_f16x2");
+  PMD_LT(ctx, hipblasLtMatmul(st->lt, p->desc, &alpha, B, p->la, A, p->lb, &beta, C, p->lc, C, p->lc, &p->algo, st->ws, st->ws_bytes, ctx->stream));
   *done = 1;
   return PMD_OK;
 }

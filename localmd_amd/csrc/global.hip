@@ -1456,25 +1456,60 @@ int pmd_gram_mtgm_impl(pmd_ctx* ctx, const float* M, int rows, int m, long ldm, 
   // fp16-piece products (gemm_f16x2.hip): both operands are split ONCE, the row blocks are views of the pieces
   bool pieces = false;
   pmd_f16x2_op ma, gb;
-  // This product stays on the fp32 path (PMD_F16X2_MTGM=3 | 2: fp16 pieces per operand, for A/B runs).  C is singular by
-  // construction on the R > frames route (its last pivot is the null direction, 3e-12 of the mean diagonal on the headline
-  // fixture) and the Cholesky step needs every other pivot positive: this is the one product of the stage whose error
-  // structure decides whether the route works at all.  Measured on that fixture (scripts/debug_headline.py): two pieces per
-  // operand (22-23 bits) fail the factorisation or pass it with wrong factors (s off by 0.57); THREE pieces hold an fp32
-  // number exactly, six of the nine piece products (down to 2^-22; the rest is 2^-33) are exact products accumulated in
+  // C is singular by construction on the R > frames route (its last pivot is the null direction, 3e-12 of the mean diagonal on
+  // the headline fixture) and the Cholesky step needs every other pivot positive: this is the one product of the stage whose
+  // error structure decides whether the route works at all.  Measured on that fixture (scripts/debug_headline.py): two fp16
+  // pieces per operand (22-23 bits) fail the factorisation or pass it with wrong factors (s off by 0.57); THREE pieces hold an
+  // fp32 number exactly, six of the nine piece products (down to 2^-22; the rest is 2^-33) are exact products accumulated in
   // fp32 - sgemm's own arithmetic - and then the length of the accumulation chain decides: chunks of 2048 / 3072 inner
-  // indices pass with the figures of the fp32 path (s 1.06e-4 / 1.13e-4, Vt 9.5e-4 / 1.2e-3 against the arbiter; sgemm,
-  // chunks of 2048: 1.11e-4, 1.2-1.5e-3), chunks of 4096 and more fail.  With three pieces and the fp32 path's chunk length
-  // the product takes 42 ms against 52 at config 3 - and 870 ms against 690 at BASELINE config 4, where 56 chunks x 6
-  // products x 5 row blocks each re-read and re-write a 330 MB block of C.  Not the default.
+  // indices pass with the figures of the fp32 path, chunks of 4096 and more fail.
+  // PMD_F16X2_MTGM: 6 (default) = those six products as ONE matrix product per chunk of pmd_gemm_k_chunk(k) inner indices
+  // (the "concatenated" form of gemm_f16x2.hip: C is revisited once per chunk, as on the fp32 path: 34 ms against 52 at
+  // config 3, s 1.18e-4 / Vt 8.5e-4 / U R 1.05e-1 against the arbiter where sgemm gives 1.11e-4 / 1.2-1.5e-3 / 5.5-6.8e-2);
+  // 3 = six separate products per chunk (42 ms at config 3, but 870 against 690 ms at BASELINE config 4: C is re-read and
+  // re-written six times per chunk); 2 = two pieces (breaks the fixture); 0 = sgemm.
   static int mtgm_pieces = -1;
   if (mtgm_pieces < 0) {
     const char* e = getenv("PMD_F16X2_MTGM");
-    mtgm_pieces = e ? atoi(e) : 0;
-    if (mtgm_pieces != 2 && mtgm_pieces != 3) mtgm_pieces = 0;
+    mtgm_pieces = e ? atoi(e) : 6;
+    if (mtgm_pieces != 2 && mtgm_pieces != 3 && mtgm_pieces != 6) mtgm_pieces = 0;
   }
-  if (mtgm_pieces && pmd_f16x2_wanted(ctx, std::min(bs, m), m, rows)) {
-    const size_t na = pmd_f16x2_bytes(m, rows, mtgm_pieces), nb = pmd_f16x2_bytes(rows, m, mtgm_pieces);
+  int pm = mtgm_pieces;
+  if (pm == 6 && pmd_f16x2_wanted(ctx, std::min(bs, m), m, rows)) {
+    // PMD_F16X2_MTGM=6: the six piece products of three exact pieces per operand as ONE matrix product per accumulation chunk
+    // (gemm_f16x2.hip, "concatenated" form): C is revisited once per chunk, as on the fp32 path, not six times
+    const float* X[2] = {Mt, GM};
+    const int xr[2] = {m, rows}, xc[2] = {rows, m};
+    const long xl[2] = {ldt, ldgm};
+    int ex[2] = {0, 0}, usable = 0;
+    RUN(pmd_f16x2_exponents(ctx, 2, X, xr, xc, xl, ex, &usable));
+    const int kc = pmd_gemm_k_chunk(rows);
+    const long lda6 = 6L * pmd_round_up(kc, 8), ldb6 = pmd_round_up(m, 8);
+    void* w = nullptr;
+    if (usable) RUN(pmd_split_scratch(ctx, ((size_t)bs * lda6 + 6 * (size_t)kc * ldb6) * sizeof(_Float16) + 512, &w));
+    const float alpha6 = ldexpf(1.f, ex[0] + ex[1]);
+    if (usable && w && std::isfinite(alpha6) && alpha6 > 0.f) {
+      _Float16* A6 = (_Float16*)w;
+      _Float16* B6 = A6 + (size_t)bs * lda6;
+      bool ok6 = true;
+      for (int k0 = 0; k0 < rows && ok6; k0 += kc) {
+        const int kk = std::min(kc, rows - k0);
+        RUN(pmd_f16cat_b(ctx, GM + (long)k0 * ldgm, kk, m, ldgm, ex[1], B6, ldb6));
+        for (int i0 = 0; i0 < m && ok6; i0 += bs) {
+          const int nr = std::min(bs, m - i0);
+          RUN(pmd_f16cat_a(ctx, Mt + (long)i0 * ldt + k0, nr, kk, ldt, ex[0], A6, lda6));
+          int done = 0;
+          RUN(pmd_f16_plain_matmul(ctx, nr, i0 + nr, 6 * kk, alpha6, A6, lda6, B6, ldb6, k0 ? 1.f : 0.f, C + (long)i0 * ldc, ldc, &done));
+          if (!done) ok6 = false;
+        }
+        if (!ok6 && k0 > 0) return pmd_fail(ctx, PMD_ERR_BLAS, "pmd_gram_mtgm", "no hipBLASLt kernel for a later chunk");
+      }
+      if (ok6) return PMD_OK;
+    }
+  }
+  if (pm == 6) pm = 0;
+  if (pm && pmd_f16x2_wanted(ctx, std::min(bs, m), m, rows)) {
+    const size_t na = pmd_f16x2_bytes(m, rows, pm), nb = pmd_f16x2_bytes(rows, m, pm);
     void* w = nullptr;
     RUN(pmd_split_scratch(ctx, na + nb, &w));
     const float* X[2] = {Mt, GM};
@@ -1484,7 +1519,7 @@ int pmd_gram_mtgm_impl(pmd_ctx* ctx, const float* M, int rows, int m, long ldm, 
     void* buf[2] = {w, (char*)w + na};
     pmd_f16x2_op ops[2];
     int usable = 0;
-    RUN(pmd_f16x2_split(ctx, 2, X, xr, xc, xl, buf, ops, &usable, mtgm_pieces));
+    RUN(pmd_f16x2_split(ctx, 2, X, xr, xc, xl, buf, ops, &usable, pm));
     if (usable) { pieces = true; ma = ops[0]; gb = ops[1]; }
     }
   }

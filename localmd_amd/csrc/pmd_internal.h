@@ -130,6 +130,12 @@ int pmd_f16x2_matmul(pmd_ctx* ctx, int tA, int tB, int m, int n, int k, float al
                      float* C, long ldc, int* done);
 int pmd_gemm_f16x2(pmd_ctx* ctx, int transA, int transB, int m, int n, int k, float alpha, const float* A, long lda, const float* B, long ldb,
                    float beta, float* C, long ldc, int* done);
+int pmd_f16x2_exponents(pmd_ctx* ctx, int count, const float* const* X, const int* rows, const int* cols, const long* ld, int* e_out,
+                        int* usable);
+int pmd_f16cat_a(pmd_ctx* ctx, const float* X, int rows, int kk, long ld, int e, _Float16* out, long ldo);
+int pmd_f16cat_b(pmd_ctx* ctx, const float* X, int kk, int cols, long ld, int e, _Float16* out, long ldo);
+int pmd_f16_plain_matmul(pmd_ctx* ctx, int m, int n, int k, float alpha, const _Float16* A, long lda, const _Float16* B, long ldb, float beta,
+                         float* C, long ldc, int* done);
 int pmd_split_scratch(pmd_ctx* ctx, size_t need, void** out);
 int pmd_split_scratch_trim(pmd_ctx* ctx, size_t keep_bytes);
 void pmd_f16x2_destroy(pmd_ctx* ctx);
