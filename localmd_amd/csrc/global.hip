@@ -1475,6 +1475,10 @@ int pmd_gram_mtgm_impl(pmd_ctx* ctx, const float* M, int rows, int m, long ldm, 
     if (mtgm_pieces != 2 && mtgm_pieces != 3 && mtgm_pieces != 6) mtgm_pieces = 0;
   }
   int pm = mtgm_pieces;
+  // (not where the output is small and the inner dimension huge - the many-tile workloads: 10^3 x 10^3 outputs, k = 3 10^5 -
+  // there one strided-batched split-K sgemm, pmd_gemm_rm, beats 150 chunks of tiny products)
+  const long out_tiles = (long)((std::min(bs, m) + 127) / 128) * ((m + 127) / 128);
+  if (pm == 6 && out_tiles < 256) pm = 0;
   if (pm == 6 && pmd_f16x2_wanted(ctx, std::min(bs, m), m, rows)) {
     // PMD_F16X2_MTGM=6: the six piece products of three exact pieces per operand as ONE matrix product per accumulation chunk
     // (gemm_f16x2.hip, "concatenated" form): C is revisited once per chunk, as on the fp32 path, not six times
