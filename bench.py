@@ -366,8 +366,9 @@ def main():
         "kernel_ms_source": "HIP events on the launch stream during one untimed instrumented step",
         "arithmetic": "fp32 operands, results and accumulation; products of >= 100 GFLOP outside the tile stage run as three "
                       "fp16-piece matrix-core products per product (two fp16 pieces per operand, power-of-two scaling, measured "
-                      "error below the sgemm path's: DESIGN 4a, tests/test_gpu_kernels.py::test_gemm_fp16_pieces); M^T G M, "
-                      "the Gram matrices and the tile stage are fp32 MFMA; PMD_GEMM_SPLIT=0 = sgemm everywhere",
+                      "error below the sgemm path's: DESIGN 4a, tests/test_gpu_kernels.py::test_gemm_fp16_pieces); M^T G M "
+                      "from three exact fp16 pieces per operand (six exact piece products as one matrix product per 2048-term "
+                      "accumulation chunk); the Gram matrices and the tile stage are fp32 MFMA; PMD_GEMM_SPLIT=0 = sgemm everywhere",
     }
     if cold_ms is not None:
         out["cold_first_step_ms"] = cold_ms   # the first call of the process (every device / pinned allocation is new)
